@@ -1,0 +1,124 @@
+/*
+ * roborugby_amd.h -- C-ABI of the MI355X-native batched RoboRugby simulator.
+ *
+ * The reference (harman097/RoboRugby) has no FFI: its boundary is the gym.Env Python API
+ * (`reset/step/get_game_state`, robo_rugby/gym_env/RR_EnvBase.py:202-216,260-297,550-559).  This
+ * header is the thin C layer beneath the Python mirror of that API (roborugby_amd/env.py): plain
+ * pointers and sizes, no torch types.  Every data pointer is a DEVICE pointer owned by the caller
+ * (PyTorch-ROCm allocations); every call is enqueued on `stream` (a hipStream_t, NULL = default
+ * stream) and returns without synchronising.  One handle per (process, device); a handle is not
+ * re-entrant.  Return value: 0 = OK, <0 = API misuse (see rr_last_error()).  Physics faults -- the
+ * places where the reference raises from inside step() -- never cross the ABI as errors: they are
+ * reported per arena in `status` (RR_STATUS_* bits).
+ *
+ * Shapes use N = num_envs, NR = nr_happy + nr_grumpy, NB = nb_pos + nb_neg.
+ */
+#ifndef ROBORUGBY_AMD_H
+#define ROBORUGBY_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RR_ABI_VERSION 1
+
+/* per-arena status bits; each mirrors one exception site of the reference */
+#define RR_STATUS_BOT_RESOLVE_FAIL 1   /* RR_EnvBase.py:313  "UNABLE TO RESOLVE BOT/BOT COLLISIONS"   */
+#define RR_STATUS_BOT_STUCK 2          /* RR_EnvBase.py:328  "ROBOTS STUCK FROM PRIOR FRAME"          */
+#define RR_STATUS_UNDO_MOVE_FAIL 4     /* RR_EnvBase.py:325  "UNABLE TO UNDO MOVE FOR ROBOT"          */
+#define RR_STATUS_UNDO_FAIL 8          /* RR_EnvBase.py:421  "UNABLE TO RESOLVE ALL COLLISIONS..."    */
+#define RR_STATUS_SAME_SPOT 16         /* RR_TrashyPhysics.py:250 balls in the exact same spot        */
+#define RR_STATUS_DIV0 32              /* MyUtils.py:25      Div0(0, 0)                               */
+#define RR_STATUS_STEP_AFTER_DONE 64   /* RR_EnvBase.py:262  "Game is over" (auto_reset = 0 only)     */
+#define RR_STATUS_BAD_ACTION 128       /* action outside 0..7 (KeyError in RR_EnvBase.py:606)         */
+#define RR_STATUS_UNDO_WARN 256        /* RR_EnvBase.py:419  GAME_MODE warning, step continued        */
+#define RR_STATUS_RESET_GAVE_UP 512    /* spawn rejection sampling hit its attempt cap                */
+#define RR_STATUS_WAS_RESET 1024       /* this call reset the arena instead of stepping it            */
+
+#define RR_DTYPE_F64 0 /* state + arithmetic in fp64: the parity mode (the reference is fp64)         */
+#define RR_DTYPE_F32 1 /* state + arithmetic in fp32: the fast mode                                   */
+
+#define RR_TEAM_HAPPY 1   /* RR_Constants.py:52 */
+#define RR_TEAM_GRUMPY (-1) /* RR_Constants.py:53 */
+
+#define RR_OBS_DIM 11 /* SingleBall_6wayLidar_v2, RR_Observers.py:394-406 */
+
+typedef struct rr_env rr_env; /* opaque */
+
+typedef struct rr_config {
+    int32_t struct_size;    /* = sizeof(rr_config), for forward compatibility                          */
+    int32_t num_envs;       /* N arenas stepped in lockstep by this handle                             */
+    int32_t nr_happy, nr_grumpy, nb_pos, nb_neg; /* RR_Constants.py:30-34; supported: (1,0,1,0), (2,2,4,4) */
+    double arena_w, arena_h;                     /* RR_Constants.py:6-7                                */
+    int32_t game_len_steps; /* RR_Constants.py:25                                                      */
+    int32_t game_mode;      /* RR_Constants.py:4: only selects the undo-loop fault rule (EnvBase:417-421) */
+    int32_t time_limit;     /* 1: done = step_count >= T (what gym's TimeLimit wrapper reports to
+                               Training_DQN_pytorch.py); 0: done = step_count > T (raw RR_EnvBase.py:555-559) */
+    int32_t auto_reset;     /* 1: rr_step on a finished arena resets it (status WAS_RESET, reward 0, done 0)
+                               instead of flagging STEP_AFTER_DONE                                     */
+    int32_t dtype;          /* RR_DTYPE_F64 | RR_DTYPE_F32                                             */
+    int32_t device;         /* HIP device ordinal                                                      */
+    uint64_t seed;          /* keys the counter-based reset RNG                                        */
+    uint64_t arena_offset;  /* global id of local arena 0: makes results invariant to sharding         */
+} rr_config;
+
+int rr_abi_version(void);
+const char *rr_last_error(void); /* thread-local description of the last <0 return */
+
+/* Allocates the per-arena state (SoA records in HBM) on cfg->device and places every arena like the
+ * reference constructor does (RR_EnvBase.py:111-116 -> _set_random_positions). */
+int rr_create(const rr_config *cfg, rr_env **out);
+int rr_destroy(rr_env *env);
+
+/* env.reset() (RR_EnvBase.py:202-216) for the arenas whose mask byte is non-zero (mask == NULL: all).
+ * obs [N,11] float32, obs_g [N,11] float32 (nullable; NaN rows when there is no grumpy robot). */
+int rr_reset(rr_env *env, const uint8_t *mask, float *obs, float *obs_g, void *stream);
+
+/* GameEnv_Simple.step (RR_EnvBase.py:617-626 -> :260-297): actions [N,na] int32 in 0..7, action i
+ * drives robot i (happy robots first); robots without an action keep their thrust.  Outputs (all
+ * nullable except obs/reward/done): obs [N,11] f32, reward [N] f32, done [N] u8, obs_g [N,11] f32,
+ * reward_g [N] f32 (info.adblGrumpyState / info.dblGrumpyScore, RR_EnvBase.py:562-566),
+ * status [N] i32. */
+int rr_step(rr_env *env, const int32_t *actions, int32_t na, float *obs, float *reward, uint8_t *done,
+            float *obs_g, float *reward_g, int32_t *status, void *stream);
+/* Same step with fp64 outputs (full-precision parity checks). */
+int rr_step_f64(rr_env *env, const int32_t *actions, int32_t na, double *obs, double *reward, uint8_t *done,
+                double *obs_g, double *reward_g, int32_t *status, void *stream);
+/* Continuous entry, GameEnv.step (RR_EnvBase.py:260-273): thrust [N,2*nk] float32 (L,R per robot),
+ * rounded half-to-even like Python's round() (RR_Robot.py:100-102). */
+int rr_step_thrust(rr_env *env, const float *thrust, int32_t nk, float *obs, float *reward, uint8_t *done,
+                   float *obs_g, float *reward_g, int32_t *status, void *stream);
+
+/* get_game_state(int_team=team) (RR_Observers.py:301-406) of the current state; robot_idx/ball_idx
+ * = -1 selects the team's first robot / positive ball 0 like the reference defaults. */
+int rr_observe(rr_env *env, int32_t team, int32_t robot_idx, int32_t ball_idx, float *obs, void *stream);
+int rr_observe_f64(rr_env *env, int32_t team, int32_t robot_idx, int32_t ball_idx, double *obs, void *stream);
+
+/* Full state exchange in the canonical fp64 layout (same as tests/golden/traj_*.npz):
+ *   robots   [N,NR,10] cx,cy,left,right,top,bottom,rot,prev_x,prev_y,prev_rot (prev = pose ring entry
+ *            moveCount-1, RR_Robot.py:43-58; NaN = absent)
+ *   robots_i [N,NR,3]  moveCount,lthrust,rthrust
+ *   balls    [N,NB,8]  cx,cy,left,right,top,bottom,vx,vy
+ *   step     [N]       lngStepCount */
+int rr_set_state(rr_env *env, const double *robots, const int32_t *robots_i, const double *balls,
+                 const int32_t *step, void *stream);
+int rr_get_state(rr_env *env, double *robots, int32_t *robots_i, double *balls, int32_t *step, void *stream);
+/* Poses only -- the reference's lst_starting_config format (RR_EnvBase.py:35-52,131-153) plus ball
+ * velocities: robots_xyr [N,NR,3], balls_xyv [N,NB,4]; edges re-derived, history cleared. */
+int rr_set_poses(rr_env *env, const double *robots_xyr, const double *balls_xyv, void *stream);
+
+/* Logging: return/length of the last finished episode and the number of finished episodes per arena
+ * (the caller accumulates `score` the same way, Training_DQN_pytorch.py:345-346). */
+int rr_episode_stats(rr_env *env, float *last_return, float *last_return_g, int32_t *last_len,
+                     int32_t *episodes_done, void *stream);
+
+/* Introspection used by bench.py for the roofline line. */
+int rr_state_bytes_per_env(const rr_env *env, int64_t *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROBORUGBY_AMD_H */

@@ -1,0 +1,67 @@
+"""Import the unmodified Python reference from /root/reference -- TEST INFRASTRUCTURE ONLY.
+
+Only usable in the build container (the reference never travels to the GPU
+box).  One preset per process: the reference's constants are module globals
+(RR_Constants.py:4 `GAME_MODE`), so preset T is obtained by exec-ing the text of
+RR_Constants.py with that one assignment flipped into a module object that is
+registered before anything else imports it.  Nothing on disk changes.
+"""
+import os
+import sys
+import types
+
+REF_ROOT = os.environ.get("RR_REFERENCE_ROOT", "/root/reference")
+
+
+def reference_available():
+    return os.path.isfile(os.path.join(REF_ROOT, "MyUtils.py"))
+
+
+def load_reference(preset):
+    """Returns a namespace with the reference modules for preset 'G' or 'T'."""
+    assert preset in ("G", "T")
+    if not reference_available():
+        raise RuntimeError("reference tree not present at %s" % REF_ROOT)
+    sys.dont_write_bytecode = True
+    here = os.path.dirname(os.path.abspath(__file__))
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    import standins
+    standins.install()
+    if REF_ROOT not in sys.path:
+        sys.path.insert(0, REF_ROOT)
+    if "robo_rugby.gym_env.RR_Constants" in sys.modules:
+        const = sys.modules["robo_rugby.gym_env.RR_Constants"]
+        have = "G" if const.GAME_MODE else "T"
+        if have != preset:
+            raise RuntimeError("reference already loaded with preset %s in this process" % have)
+    elif preset == "T":
+        pkg = types.ModuleType("robo_rugby")
+        pkg.__path__ = [os.path.join(REF_ROOT, "robo_rugby")]
+        sub = types.ModuleType("robo_rugby.gym_env")
+        sub.__path__ = [os.path.join(REF_ROOT, "robo_rugby", "gym_env")]
+        path = os.path.join(REF_ROOT, "robo_rugby", "gym_env", "RR_Constants.py")
+        text = open(path).read()
+        assert text.count("GAME_MODE = True") == 1
+        text = text.replace("GAME_MODE = True", "GAME_MODE = False", 1)
+        const = types.ModuleType("robo_rugby.gym_env.RR_Constants")
+        const.__file__ = path
+        exec(compile(text, path, "exec"), const.__dict__)
+        sys.modules["robo_rugby"] = pkg
+        sys.modules["robo_rugby.gym_env"] = sub
+        sys.modules["robo_rugby.gym_env.RR_Constants"] = const
+        sub.RR_Constants = const
+    import MyUtils
+    import robo_rugby.gym_env.RR_Constants as const
+    import robo_rugby.gym_env.RR_EnvBase as base
+    import robo_rugby.gym_env.RR_TrashyPhysics as tp
+    import robo_rugby.gym_env.RR_Environments as envs
+    import robo_rugby.gym_env.RR_Robot as robot
+    import robo_rugby.gym_env.RR_Ball as ball
+    import robo_rugby.gym_env.RR_Goal as goal
+    import robo_rugby.gym_env.RR_ScoreKeepers as sk
+    import robo_rugby.gym_env.RR_Observers as obs
+    assert bool(const.GAME_MODE) == (preset == "G")
+    ns = types.SimpleNamespace(MyUtils=MyUtils, const=const, base=base, tp=tp, envs=envs, robot=robot,
+                               ball=ball, goal=goal, sk=sk, obs=obs, preset=preset)
+    return ns

@@ -1,0 +1,1133 @@
+// rr_sim.hpp -- wave-per-arena lockstep simulator core for gfx950 (CDNA4).
+//
+// One 64-lane wavefront owns one arena.  The arena's persistent record (SoA over entities) is
+// pulled from HBM into the wave's LDS slice with coalesced loads, the 12 physics sub-steps of
+// GameEnv.step (reference RR_EnvBase.py:275-287) run out of LDS, and the record is written back.
+// Inside a sub-step the all-pairs contact sweeps are spread over lanes (one lane per
+// (pair, side, side) or (ball, robot, diameter) task) and reduced with a wavefront ballot; the
+// contact RESPONSES mutate state that the next response reads (RR_EnvBase.py:373-388), so they are
+// applied in the reference's list order by wave-uniform code that walks the ballot mask.
+//
+// The source is written against three tiny macros (RR_FOR_LANES / RR_SYNC / RR_VOTE) so that the
+// very same phases can also be compiled by g++ as a lane loop: tests/emu builds that variant to
+// debug the phase logic against the CPU oracle without a GPU.  It is a test harness only -- the
+// product library is the HIP build and nothing else.
+//
+// Real = double is the parity mode (the reference computes in Python floats = fp64); Real = float
+// is the fast mode.  Incremental edge bookkeeping (MyUtils.py:141-148), int-truncated wall rects
+// (RR_Ball.py:8-15) and Python's float-% are reproduced so that knife-edge branches agree with the
+// reference; the only deliberate deviations are the ~1e-13 "copy()" and module-global scratch-rect
+// noises listed in DESIGN.md.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define RR_GPU 1
+#else
+#define RR_GPU 0
+#endif
+
+#if defined(__HIPCC__)
+#define RR_HD __host__ __device__ __forceinline__
+#define RR_HDN __host__ __device__ __noinline__
+#else
+#define RR_HD inline
+#define RR_HDN
+#endif
+
+#if RR_GPU
+#define RR_LANE_ID() ((int)(threadIdx.x & 63))
+#define RR_FOR_LANES(l) for (int l = RR_LANE_ID(), l##_o = 0; l##_o < 1; ++l##_o)
+#define RR_IS_LANE0 (RR_LANE_ID() == 0)
+// LDS is only shared inside the wave: a wavefront-scope release/acquire pair orders it
+#define RR_SYNC()                                                    \
+    do {                                                             \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       \
+        __builtin_amdgcn_wave_barrier();                             \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
+    } while (0)
+#define RR_VOTE(mask, l, pred) (mask) = __ballot(pred)
+#else
+#define RR_FOR_LANES(l) for (int l = 0; l < 64; ++l)
+#define RR_IS_LANE0 true
+#define RR_SYNC() do { } while (0)
+#define RR_VOTE(mask, l, pred) (mask) |= ((uint64_t)((pred) ? 1 : 0)) << (l)
+#endif
+
+namespace rr {
+
+enum : int {
+    ST_BOT_RESOLVE_FAIL = 1, ST_BOT_STUCK = 2, ST_UNDO_MOVE_FAIL = 4, ST_UNDO_FAIL = 8, ST_SAME_SPOT = 16,
+    ST_DIV0 = 32, ST_STEP_AFTER_DONE = 64, ST_BAD_ACTION = 128, ST_UNDO_WARN = 256, ST_RESET_GAVE_UP = 512,
+    ST_WAS_RESET = 1024
+};
+
+// ------------------------------------------------------------------------------------------------ math
+RR_HD double m_sin(double x) { return ::sin(x); }
+RR_HD double m_cos(double x) { return ::cos(x); }
+RR_HD double m_atan(double x) { return ::atan(x); }
+RR_HD double m_sqrt(double x) { return ::sqrt(x); }
+RR_HD double m_fmod(double a, double b) { return ::fmod(a, b); }
+RR_HD double m_abs(double x) { return ::fabs(x); }
+RR_HD double m_rint(double x) { return ::rint(x); }
+RR_HD float m_sin(float x) { return ::sinf(x); }
+RR_HD float m_cos(float x) { return ::cosf(x); }
+RR_HD float m_atan(float x) { return ::atanf(x); }
+RR_HD float m_sqrt(float x) { return ::sqrtf(x); }
+RR_HD float m_fmod(float a, float b) { return ::fmodf(a, b); }
+RR_HD float m_abs(float x) { return ::fabsf(x); }
+RR_HD float m_rint(float x) { return ::rintf(x); }
+
+template <typename R> RR_HD R inf_() { return (R)INFINITY; }
+template <typename R> RR_HD bool is_inf(R x) { return x == inf_<R>() || x == -inf_<R>(); }
+template <typename R> RR_HD bool is_nan(R x) { return x != x; }
+template <typename R> RR_HD R pi_() { return (R)3.14159265358979323846; }
+template <typename R> RR_HD R radians(R x) { return x * (pi_<R>() / (R)180.0); } // math.radians
+template <typename R> RR_HD R degrees(R x) { return x * ((R)180.0 / pi_<R>()); } // math.degrees
+template <typename R> RR_HD R py_mod(R a, R b) {                                 // Python float %
+    R m = m_fmod(a, b);
+    if (m != (R)0) {
+        if ((b < (R)0) != (m < (R)0)) m += b;
+    } else {
+        m = (R)0;
+    }
+    return m;
+}
+template <typename R> RR_HD R py_max(R a, R b) { return (b > a) ? b : a; } // first maximal wins
+template <typename R> RR_HD R py_min(R a, R b) { return (b < a) ? b : a; }
+
+template <typename R> struct V2 { R x, y; };
+template <typename R> struct Seg { V2<R> a, b; };
+
+// MyUtils.py:17-25.  0/0 raises in the reference -> status bit + 0
+template <typename R> RR_HD R div0(R n, R d, int &st) {
+    if (d != (R)0) return n / d;
+    if (n > (R)0) return inf_<R>();
+    if (n < (R)0) return -inf_<R>();
+    st |= ST_DIV0;
+    return (R)0;
+}
+// MyUtils.py:40-41
+template <typename R> RR_HD R dist(V2<R> a, V2<R> b) {
+    R dx = b.x - a.x, dy = b.y - a.y;
+    return m_sqrt(dx * dx + dy * dy);
+}
+// MyUtils.py:44-58
+template <typename R> RR_HD void slope_yint(V2<R> a, V2<R> b, R &m, R &c, int &st) {
+    m = div0<R>(b.y - a.y, b.x - a.x, st);
+    if (m == inf_<R>()) c = -inf_<R>();
+    else if (m == -inf_<R>()) c = inf_<R>();
+    else c = a.y - a.x * m;
+}
+// MyUtils.py:61-85 with the two slope/intercept pairs already known
+template <typename R> RR_HD V2<R> intersect_mb(R m1, R b1, R x1, R m2, R b2, R x2) {
+    V2<R> r;
+    if (m1 == m2 || (is_inf(m1) && is_inf(m2))) { r.x = inf_<R>(); r.y = inf_<R>(); return r; }
+    if (is_inf(m1)) {
+        r.x = x1;
+        r.y = m2 * r.x + b2;
+    } else if (is_inf(m2)) {
+        r.x = x2;
+        r.y = m1 * r.x + b1;
+    } else {
+        r.x = (b1 - b2) / (m2 - m1);
+        if (m_abs(b1) < m_abs(b2)) r.y = m1 * r.x + b1;
+        else r.y = m2 * r.x + b2;
+    }
+    return r;
+}
+template <typename R> RR_HD V2<R> line_intersection(Seg<R> l1, Seg<R> l2, int &st) {
+    R m1, b1, m2, b2;
+    slope_yint(l1.a, l1.b, m1, b1, st);
+    slope_yint(l2.a, l2.b, m2, b2, st);
+    return intersect_mb<R>(m1, b1, l1.a.x, m2, b2, l2.a.x);
+}
+// MyUtils.py:88-94
+template <typename R> RR_HD bool within(V2<R> p, Seg<R> l, R buf) {
+    return ((l.a.x - buf <= p.x && p.x <= l.b.x + buf) || (l.b.x - buf <= p.x && p.x <= l.a.x + buf)) &&
+           ((l.a.y - buf <= p.y && p.y <= l.b.y + buf) || (l.b.y - buf <= p.y && p.y <= l.a.y + buf));
+}
+// MyUtils.py:97-110
+template <typename R> RR_HD R angle_degrees(V2<R> a, V2<R> b, int &st) {
+    R dy = b.y - a.y, dx = b.x - a.x;
+    R ang = m_atan(div0<R>(dy, dx, st));
+    if (dx < (R)0) ang += pi_<R>();
+    return py_mod<R>(degrees<R>((R)2 * pi_<R>() - ang) + (R)720, (R)360);
+}
+
+// ------------------------------------------------------------------------------------------------ config
+template <int NRH_, int NRG_, int NBP_, int NBN_, typename Real_> struct Cfg {
+    static constexpr int NRH = NRH_, NRG = NRG_, NBP = NBP_, NBN = NBN_;
+    static constexpr int NR = NRH_ + NRG_, NB = NBP_ + NBN_;
+    static constexpr int NPR = NR * (NR - 1) / 2; // robot pairs
+    static constexpr int NPB = NB * (NB - 1) / 2; // ball pairs
+    using Real = Real_;
+    static_assert(NR >= 1 && NR <= 5, "lidar lane mapping needs 12*NR <= 64");
+    static_assert(NB >= 1 && NB * NR <= 32, "ball x robot x diameter tasks must fit 64 lanes");
+    static_assert(NPB <= 64, "ball pairs must fit one wave");
+};
+
+template <typename R> struct SimParams {
+    R W, H;
+    R mult_ball, mult_robot;     // RR_Constants.py:46,50
+    R rob_cdist;                 // FloatRect._corner_dist of a 20x40 rect (MyUtils.py:138)
+    R inner_h, inner_cdist;      // half side / corner dist of _rectBallInner (RR_TrashyPhysics.py:29-35)
+    int32_t game_len, game_mode, time_limit, auto_reset;
+    uint64_t seed, arena_offset;
+};
+
+// corner / side numbering of FloatRect (MyUtils.py:326-336, :209-229)
+enum { TL = 0, TR = 1, BL = 2, BR = 3 };
+RR_HD int side_a(int s) { return s == 0 ? TR : s == 1 ? TL : s == 2 ? BL : BR; } // RIGHT,TOP,LEFT,BOTTOM
+RR_HD int side_b(int s) { return s == 0 ? BR : s == 1 ? TR : s == 2 ? TL : BL; }
+
+// ------------------------------------------------------------------------------------------------ arena (LDS image)
+template <class C> struct Arena {
+    using R = typename C::Real;
+    static constexpr int NR = C::NR, NB = C::NB;
+    // ---- persistent: identical order to the HBM record (field-major = SoA over the entities)
+    struct P {
+        R rcx[NR], rcy[NR], rl[NR], rrt[NR], rt[NR], rb[NR], rrot[NR], px[NR], py[NR], prot[NR];
+        R bcx[NB], bcy[NB], bl[NB], brt[NB], bt[NB], bb[NB], bvx[NB], bvy[NB];
+        R acc[4]; // running return happy/grumpy, last finished return happy/grumpy
+    } p;
+    struct I {
+        int32_t mc[NR], thl[NR], thr[NR];
+        int32_t step, episode, ep_len, ep_count, last_len;
+    } i;
+    // ---- per-step scratch
+    R rel[NR][8];   // corner offsets TL,TR,BL,BR (x,y) for the current rotation
+    R irel[NR][8];  // corner offsets of the ball's inner square at rot+45 (diameter end points)
+    R irot[NR];     // rotation irel was built for (NaN = stale)
+    R ax[NR], ay[NR], arot[NR], arel[NR][8]; // pose at frame begin (= ring entry written this frame)
+    R prel[NR][8];  // corner offsets for the persisted previous-move pose (px,py,prot)
+    R psx[NR], psy[NR]; // robot centre at step begin (rectDblPriorStep)
+    R bfx[NB], bfy[NB], pfx[NB], pfy[NB];
+    int32_t bmass[NB];
+    R lf[3 * 4 * NR], lb[3 * 4 * NR]; // lidar candidates
+    static constexpr int P_REALS = (int)(sizeof(P) / sizeof(R));
+    static constexpr int I_INTS = (int)(sizeof(I) / sizeof(int32_t));
+    static constexpr int P_STRIDE = (P_REALS + 15) / 16 * 16; // record strides in HBM (128-B multiples)
+    static constexpr int I_STRIDE = (I_INTS + 15) / 16 * 16;
+};
+
+// ------------------------------------------------------------------------------------------------ FloatRect in registers
+template <typename R> struct FR {
+    R cx, cy, l, r, t, b, rot;
+    R rel[8];
+};
+template <typename R> RR_HD void fr_move(FR<R> &f, R dx, R dy) { // MyUtils.py:141-148
+    f.cx += dx; f.l += dx; f.r += dx;
+    f.cy += dy; f.t += dy; f.b += dy;
+}
+template <typename R> RR_HD void fr_set_left(FR<R> &f, R v) { fr_move<R>(f, v - f.l, (R)0); }
+template <typename R> RR_HD void fr_set_right(FR<R> &f, R v) { fr_move<R>(f, v - f.r, (R)0); }
+template <typename R> RR_HD void fr_set_top(FR<R> &f, R v) { fr_move<R>(f, (R)0, v - f.t); }
+template <typename R> RR_HD void fr_set_bottom(FR<R> &f, R v) { fr_move<R>(f, (R)0, v - f.b); }
+template <typename R> RR_HD void fr_set_cx(FR<R> &f, R v) { fr_move<R>(f, v - f.cx, (R)0); }
+template <typename R> RR_HD void fr_set_cy(FR<R> &f, R v) { fr_move<R>(f, (R)0, v - f.cy); }
+
+// body of the rotation setter (MyUtils.py:284-316): rotate the initial corners (+-hw, +-hh) by
+// 360-rot degrees and renormalise them to the corner distance
+template <typename R> RR_HD void corners_for(R rot, R hw, R hh, R cdist, R *rel) {
+    const R ix[4] = { -hw, hw, -hw, hw }, iy[4] = { -hh, -hh, hh, hh };
+    if (rot == (R)0) {
+        for (int k = 0; k < 4; k++) { rel[2 * k] = ix[k]; rel[2 * k + 1] = iy[k]; }
+        return;
+    }
+    R rad = radians<R>((R)360 - rot);
+    R c = m_cos(rad), s = m_sin(rad);
+    for (int k = 0; k < 4; k++) {
+        R qx = ix[k] * c - iy[k] * s, qy = ix[k] * s + iy[k] * c;
+        R d = m_sqrt(qx * qx + qy * qy);
+        rel[2 * k] = qx * cdist / d;
+        rel[2 * k + 1] = qy * cdist / d;
+    }
+}
+template <typename R> RR_HD void fr_edges_from_rel(FR<R> &f) { // MyUtils.py:318-322
+    R mnx = f.rel[0], mxx = f.rel[0], mny = f.rel[1], mxy = f.rel[1];
+    for (int k = 1; k < 4; k++) {
+        R x = f.rel[2 * k], y = f.rel[2 * k + 1];
+        if (x < mnx) mnx = x;
+        if (x > mxx) mxx = x;
+        if (y < mny) mny = y;
+        if (y > mxy) mxy = y;
+    }
+    f.l = mnx + f.cx; f.r = mxx + f.cx; f.t = mny + f.cy; f.b = mxy + f.cy;
+}
+template <typename R> RR_HD void fr_set_rot(FR<R> &f, R nr, R cdist) { // robot rect: 20 x 40
+    nr = py_mod<R>(nr + (R)720, (R)360);
+    if (nr == f.rot) return;
+    f.rot = nr;
+    corners_for<R>(nr, (R)10, (R)20, cdist, f.rel);
+    fr_edges_from_rel<R>(f);
+}
+
+template <class C> RR_HD FR<typename C::Real> load_robot(const Arena<C> &A, int r) {
+    FR<typename C::Real> f;
+    f.cx = A.p.rcx[r]; f.cy = A.p.rcy[r]; f.l = A.p.rl[r]; f.r = A.p.rrt[r]; f.t = A.p.rt[r]; f.b = A.p.rb[r];
+    f.rot = A.p.rrot[r];
+    for (int k = 0; k < 8; k++) f.rel[k] = A.rel[r][k];
+    return f;
+}
+template <class C> RR_HD void store_robot(Arena<C> &A, int r, const FR<typename C::Real> &f) {
+    A.p.rcx[r] = f.cx; A.p.rcy[r] = f.cy; A.p.rl[r] = f.l; A.p.rrt[r] = f.r; A.p.rt[r] = f.t; A.p.rb[r] = f.b;
+    A.p.rrot[r] = f.rot;
+    for (int k = 0; k < 8; k++) A.rel[r][k] = f.rel[k];
+}
+template <class C> RR_HD V2<typename C::Real> robot_corner(const Arena<C> &A, int r, int c) {
+    V2<typename C::Real> v = { A.p.rcx[r] + A.rel[r][2 * c], A.p.rcy[r] + A.rel[r][2 * c + 1] };
+    return v;
+}
+template <class C> RR_HD Seg<typename C::Real> robot_side(const Arena<C> &A, int r, int s) {
+    Seg<typename C::Real> g = { robot_corner(A, r, side_a(s)), robot_corner(A, r, side_b(s)) };
+    return g;
+}
+
+// ball rect helpers (rotation is always 0 for balls): incremental edges like the reference
+template <class C> RR_HD void ball_shift(Arena<C> &A, int b, typename C::Real dx, typename C::Real dy) {
+    A.p.bcx[b] += dx; A.p.bl[b] += dx; A.p.brt[b] += dx;
+    A.p.bcy[b] += dy; A.p.bt[b] += dy; A.p.bb[b] += dy;
+}
+
+// ------------------------------------------------------------------------------------------------ robot kinematics (RR_Robot.py:139-234)
+template <typename R> RR_HD bool rob_hit_wall(const FR<R> &f, const SimParams<R> &sp) {
+    return f.l < (R)0 || f.r > sp.W || f.t <= (R)0 || f.b >= sp.H;
+}
+template <typename R> RR_HD void rob_clamp(FR<R> &f, const SimParams<R> &sp) {
+    const R buffer = (R).5;
+    if (f.l < (R)0) fr_set_left<R>(f, buffer);
+    if (f.r > sp.W) fr_set_right<R>(f, sp.W - buffer);
+    if (f.t <= (R)0) fr_set_top<R>(f, buffer);
+    if (f.b >= sp.H) fr_set_bottom<R>(f, sp.H - buffer);
+}
+template <typename R> RR_HD void rob_move_linear(FR<R> &f, const SimParams<R> &sp, R vel) {
+    R rad = radians<R>(f.rot);
+    R px = f.cx, py = f.cy;
+    fr_set_left<R>(f, f.l + m_cos(rad) * vel);
+    fr_set_top<R>(f, f.t + m_sin(rad) * vel * (R)-1);
+    if (rob_hit_wall<R>(f, sp)) { fr_set_cx<R>(f, px); fr_set_cy<R>(f, py); }
+    rob_clamp<R>(f, sp);
+}
+template <typename R> RR_HD void rob_move_angular(FR<R> &f, const SimParams<R> &sp, R w, bool has_c, V2<R> c, R adj) {
+    R rot_prior = f.rot, px = f.cx, py = f.cy;
+    fr_set_rot<R>(f, f.rot + w, sp.rob_cdist);
+    if (has_c) {
+        R rad = radians<R>(f.rot + adj);
+        fr_set_cx<R>(f, c.x + (R)16 * m_cos(rad));
+        fr_set_cy<R>(f, c.y - (R)16 * m_sin(rad));
+    }
+    if (rob_hit_wall<R>(f, sp)) {
+        fr_set_cx<R>(f, px); fr_set_cy<R>(f, py);
+        fr_set_rot<R>(f, rot_prior, sp.rob_cdist);
+    }
+    rob_clamp<R>(f, sp);
+}
+template <class C> RR_HD void robot_move_lane(Arena<C> &A, const SimParams<typename C::Real> &sp, int r) {
+    using R = typename C::Real;
+    const int L = A.i.thl[r], Rt = A.i.thr[r];
+    A.i.mc[r] += 1;
+    if (L == Rt && L == 0) return;
+    FR<R> f = load_robot(A, r);
+    if (L == Rt) {
+        rob_move_linear<R>(f, sp, L < 0 ? (R)-1 : (R)1);
+    } else if (L + Rt == 0) {
+        V2<R> z = { (R)0, (R)0 };
+        rob_move_angular<R>(f, sp, Rt > 0 ? (R)1.2 : (R)-1.2, false, z, (R)0);
+    } else {
+        R w = (Rt > 0 || L < 0) ? (R).6 : (R)-.6;
+        R off = (Rt != 0) ? (R)90 : (R)-90; // pivot = left track (rot+90) when the right one drives
+        R rad = radians<R>(f.rot + off);
+        V2<R> c = { f.cx + (R)16 * m_cos(rad), f.cy - (R)16 * m_sin(rad) };
+        rob_move_angular<R>(f, sp, w, true, c, -off);
+    }
+    store_robot(A, r, f);
+}
+// Robot.undo_move (RR_Robot.py:110-137): back to the pose stored at frame begin
+template <class C> RR_HD void robot_undo_lane(Arena<C> &A, int r) {
+    using R = typename C::Real;
+    FR<R> f = load_robot(A, r);
+    fr_set_cx<R>(f, A.ax[r]);
+    fr_set_cy<R>(f, A.ay[r]);
+    R nr = py_mod<R>(A.arot[r] + (R)720, (R)360);
+    if (nr != f.rot) {
+        f.rot = nr;
+        for (int k = 0; k < 8; k++) f.rel[k] = A.arel[r][k];
+        fr_edges_from_rel<R>(f);
+    }
+    store_robot(A, r, f);
+    A.i.mc[r] -= 1;
+}
+// inner-square corner offsets for robot r at rot+45 (RR_TrashyPhysics.py:54-55,93)
+template <class C> RR_HD void refresh_inner_lane(Arena<C> &A, const SimParams<typename C::Real> &sp, int r) {
+    using R = typename C::Real;
+    R rot = A.p.rrot[r];
+    if (A.irot[r] == rot) return;
+    A.irot[r] = rot;
+    corners_for<R>(py_mod<R>(rot + (R)45 + (R)720, (R)360), sp.inner_h, sp.inner_h, sp.inner_cdist, A.irel[r]);
+}
+
+// ------------------------------------------------------------------------------------------------ contact predicates, one task per lane
+// robots_collided (RR_TrashyPhysics.py:18-24): task = (pair, side of bot1, side of bot2)
+template <class C> RR_HD void pair_of(int p, int n, int &i, int &j) { // p-th (i<j) pair in nested-loop order
+    i = 0;
+    while (p >= n - 1 - i) { p -= n - 1 - i; i++; }
+    j = i + 1 + p;
+}
+template <class C> RR_HD uint32_t detect_robot_pairs(const Arena<C> &A) {
+    using R = typename C::Real;
+    uint32_t pairs = 0;
+    constexpr int NT = C::NPR * 16;
+    for (int base = 0; base < NT; base += 64) {
+        uint64_t m = 0;
+        RR_FOR_LANES(l) {
+            bool hit = false;
+            int t = base + l;
+            if (t < NT) {
+                int i, j, st = 0;
+                pair_of<C>(t >> 4, C::NR, i, j);
+                Seg<R> s1 = robot_side(A, i, (t >> 2) & 3), s2 = robot_side(A, j, t & 3);
+                V2<R> p = line_intersection<R>(s1, s2, st);
+                hit = within<R>(p, s1, (R)0) && within<R>(p, s2, (R)0);
+            }
+            RR_VOTE(m, l, hit);
+        }
+        for (int q = 0; q < 4; q++)
+            if ((m >> (16 * q)) & 0xFFFFull) pairs |= 1u << ((base >> 4) + q);
+    }
+    return pairs;
+}
+// ball_robot_collided (RR_TrashyPhysics.py:39-69): task = (ball, robot, diameter); each lane tests two
+// corners against the radius and its diameter against the four sides.  Bit (b*NR + r) of the result.
+template <class C> RR_HD uint32_t detect_ball_robot(const Arena<C> &A) {
+    using R = typename C::Real;
+    constexpr int NT = C::NB * C::NR * 2;
+    uint64_t m = 0;
+    RR_FOR_LANES(l) {
+        bool hit = false;
+        if (l < NT) {
+            int d = l & 1, pr = l >> 1, r = pr % C::NR, b = pr / C::NR, st = 0;
+            V2<R> bc = { A.p.bcx[b], A.p.bcy[b] };
+            hit = dist<R>(robot_corner(A, r, 2 * d), bc) < (R)7 || dist<R>(robot_corner(A, r, 2 * d + 1), bc) < (R)7;
+            // diameters (TL->BR) and (TR->BL) of the inner square
+            int ca = d == 0 ? TL : TR, cb = d == 0 ? BR : BL;
+            Seg<R> dia = { { bc.x + A.irel[r][2 * ca], bc.y + A.irel[r][2 * ca + 1] },
+                           { bc.x + A.irel[r][2 * cb], bc.y + A.irel[r][2 * cb + 1] } };
+            R md, cd;
+            slope_yint<R>(dia.a, dia.b, md, cd, st);
+            for (int s = 0; s < 4; s++) {
+                Seg<R> side = robot_side(A, r, s);
+                R ms, cs;
+                slope_yint<R>(side.a, side.b, ms, cs, st);
+                V2<R> p = intersect_mb<R>(ms, cs, side.a.x, md, cd, dia.a.x);
+                hit = hit || (within<R>(p, side, (R)0) && within<R>(p, dia, (R)0));
+            }
+        }
+        RR_VOTE(m, l, hit);
+    }
+    uint32_t pairs = 0;
+    for (int q = 0; q < C::NB * C::NR; q++)
+        if ((m >> (2 * q)) & 3ull) pairs |= 1u << q;
+    return pairs;
+}
+// balls_collided (RR_TrashyPhysics.py:72-73): one lane per ball pair
+template <class C> RR_HD uint64_t detect_ball_pairs(const Arena<C> &A) {
+    using R = typename C::Real;
+    uint64_t m = 0;
+    if (C::NPB == 0) return 0;
+    RR_FOR_LANES(l) {
+        bool hit = false;
+        if (l < C::NPB) {
+            int i, j;
+            pair_of<C>(l, C::NB, i, j);
+            V2<R> a = { A.p.bcx[i], A.p.bcy[i] }, b = { A.p.bcx[j], A.p.bcy[j] };
+            hit = dist<R>(a, b) <= (R)14;
+        }
+        RR_VOTE(m, l, hit);
+    }
+    return m;
+}
+// collided_wall on the int-truncated rect (RR_TrashyPhysics.py:76-85, RR_Ball.py:8-15)
+template <class C> RR_HD bool ball_collided_wall(const Arena<C> &A, const SimParams<typename C::Real> &sp, int b) {
+    long L = (long)A.p.bl[b], T = (long)A.p.bt[b];
+    long Wd = (long)(A.p.brt[b] - A.p.bl[b]), Ht = (long)(A.p.bb[b] - A.p.bt[b]);
+    return L < 0 || L + Wd > (long)sp.W || T < 0 || T + Ht > (long)sp.H;
+}
+template <class C> RR_HD uint32_t detect_ball_wall(const Arena<C> &A, const SimParams<typename C::Real> &sp) {
+    uint64_t m = 0;
+    RR_FOR_LANES(l) {
+        bool hit = (l < C::NB) && ball_collided_wall(A, sp, l);
+        RR_VOTE(m, l, hit);
+    }
+    return (uint32_t)m;
+}
+
+// ------------------------------------------------------------------------------------------------ contact responses (wave-uniform, list order)
+// rectDblPriorFrame (RR_Robot.py:43-58): pose at the start of the robot's last move that was not undone
+template <class C>
+RR_HD void robot_prev_frame(const Arena<C> &A, int r, uint32_t bots_moved, typename C::Real &x, typename C::Real &y,
+                            const typename C::Real *&rel) {
+    if (bots_moved & (1u << r)) { x = A.ax[r]; y = A.ay[r]; rel = A.arel[r]; }
+    else if (!is_nan(A.p.px[r])) { x = A.p.px[r]; y = A.p.py[r]; rel = A.prel[r]; }
+    else { x = A.p.rcx[r]; y = A.p.rcy[r]; rel = A.rel[r]; }
+}
+template <class C> RR_HD void force_diameters(const Arena<C> &A, int r, V2<typename C::Real> bc, Seg<typename C::Real> dia[2]) {
+    // (BL->TR) and (BR->TL), RR_TrashyPhysics.py:95-104
+    const typename C::Real *q = A.irel[r];
+    dia[0].a = { bc.x + q[2 * BL], bc.y + q[2 * BL + 1] }; dia[0].b = { bc.x + q[2 * TR], bc.y + q[2 * TR + 1] };
+    dia[1].a = { bc.x + q[2 * BR], bc.y + q[2 * BR + 1] }; dia[1].b = { bc.x + q[2 * TL], bc.y + q[2 * TL + 1] };
+}
+// apply_force_to_ball (RR_TrashyPhysics.py:88-152)
+template <class C> RR_HDN void apply_force_to_ball(Arena<C> &A, int r, int b, uint32_t bots_moved, int &st) {
+    using R = typename C::Real;
+    const R cbuf = (R).5;
+    V2<R> bc = { A.p.bcx[b], A.p.bcy[b] }, rc = { A.p.rcx[r], A.p.rcy[r] };
+    Seg<R> dia[2];
+    force_diameters(A, r, bc, dia);
+    R fx = A.bfx[b], fy = A.bfy[b];
+    bool done = false;
+    for (int s = 0; s < 4 && !done; s++) {
+        Seg<R> side = robot_side(A, r, s);
+        for (int d = 0; d < 2 && !done; d++) {
+            V2<R> I = line_intersection<R>(side, dia[d], st);
+            if (within<R>(I, side, (R)0) && within<R>(I, dia[d], cbuf)) {
+                R da = dist<R>(dia[d].a, rc), db = dist<R>(dia[d].b, rc);
+                V2<R> cp = (da < db) ? dia[d].a : dia[d].b, opp = (da >= db) ? dia[d].a : dia[d].b;
+                fx += (I.x - cp.x) + (opp.x - cp.x) * cbuf / (R)14;
+                fy += (I.y - cp.y) + (opp.y - cp.y) * cbuf / (R)14;
+                done = true;
+            }
+        }
+    }
+    if (!done) {
+        R px, py; const R *prel;
+        robot_prev_frame(A, r, bots_moved, px, py, prel);
+        for (int c = 0; c < 4 && !done; c++) {
+            V2<R> bcn = robot_corner(A, r, c);
+            R dc = dist<R>(bcn, bc);
+            if (dc < (R)7 + cbuf) {
+                V2<R> pc = { px + prel[2 * c], py + prel[2 * c + 1] };
+                V2<R> con = { bc.x - (bcn.x * (R)3 + pc.x) / (R)4, bc.y - (bcn.y * (R)3 + pc.y) / (R)4 };
+                R cd = m_sqrt(con.x * con.x + con.y * con.y);
+                R ex = ((R)7 - dc) * (R)1.2;
+                fx += (con.x * ex / cd) + con.x * cbuf / cd;
+                fy += (con.y * ex / cd) + con.y * cbuf / cd;
+                done = true;
+            }
+        }
+    }
+    if (done && RR_IS_LANE0) {
+        A.bfx[b] = fx; A.bfy[b] = fy;
+        if (A.bmass[b] < 2) A.bmass[b] = 2; // max(MASS_ROBOT, ball mass)
+    }
+    RR_SYNC();
+}
+template <typename R> RR_HD void bounce_reflect(V2<R> con, R &vx, R &vy, R &d2) { // RR_TrashyPhysics.py:192-204
+    d2 = con.x * con.x + con.y * con.y;
+    R term = ((con.x * vx) + (con.y * vy)) / d2;
+    R prx = term * con.x, pry = term * con.y;
+    if ((prx < (R)0 && con.x > (R)0) || (prx > (R)0 && con.x < (R)0)) vx = -prx * (R).8 * (R).8;
+    if ((pry < (R)0 && con.y > (R)0) || (pry > (R)0 && con.y < (R)0)) vy = -pry * (R).8 * (R).8;
+}
+// bounce_ball_off_bot (RR_TrashyPhysics.py:155-245)
+template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, int r, int b, uint32_t bots_moved, int &st) {
+    using R = typename C::Real;
+    R vx = A.p.bvx[b], vy = A.p.bvy[b];
+    if (vx == (R)0 && vy == (R)0) return;
+    const R cbuf = (R).5;
+    V2<R> bc = { A.p.bcx[b], A.p.bcy[b] };
+    Seg<R> dia[2];
+    force_diameters(A, r, bc, dia);
+    R px, py; const R *prel;
+    robot_prev_frame(A, r, bots_moved, px, py, prel);
+    R mvx = 0, mvy = 0;
+    bool done = false;
+    for (int s = 0; s < 4 && !done; s++) {
+        Seg<R> side = robot_side(A, r, s);
+        int ca = side_a(s), cb = side_b(s);
+        Seg<R> sprev = { { px + prel[2 * ca], py + prel[2 * ca + 1] }, { px + prel[2 * cb], py + prel[2 * cb + 1] } };
+        for (int d = 0; d < 2 && !done; d++) {
+            V2<R> I = line_intersection<R>(side, dia[d], st);
+            if (within<R>(I, side, (R)0) && within<R>(I, dia[d], (R)0)) {
+                V2<R> Ip = line_intersection<R>(sprev, dia[d], st);
+                R da = dist<R>(dia[d].a, Ip), db = dist<R>(dia[d].b, Ip);
+                V2<R> cp = (da < db) ? dia[d].a : dia[d].b, opp = (da >= db) ? dia[d].a : dia[d].b;
+                V2<R> con = { opp.x - cp.x, opp.y - cp.y };
+                R d2;
+                bounce_reflect<R>(con, vx, vy, d2);
+                R sq = m_sqrt(d2);
+                mvx = (I.x - cp.x) + con.x * cbuf / sq;
+                mvy = (I.y - cp.y) + con.y * cbuf / sq;
+                done = true;
+            }
+        }
+    }
+    for (int c = 0; c < 4 && !done; c++) {
+        V2<R> bcn = robot_corner(A, r, c);
+        R dc = dist<R>(bcn, bc);
+        if (dc < (R)7) {
+            V2<R> pc = { px + prel[2 * c], py + prel[2 * c + 1] };
+            V2<R> con = { bc.x - (bcn.x * (R)3 + pc.x) / (R)4, bc.y - (bcn.y * (R)3 + pc.y) / (R)4 };
+            R d2;
+            bounce_reflect<R>(con, vx, vy, d2);
+            R ex = dist<R>(pc, bc), cd = m_sqrt(d2);
+            mvx = con.x * ex / cd;
+            mvy = con.y * ex / cd;
+            done = true;
+        }
+    }
+    if (done && RR_IS_LANE0) {
+        A.p.bvx[b] = vx; A.p.bvy[b] = vy;
+        // `centerx += v` goes through the setter: the applied delta is (cx + v) - cx
+        R nx = bc.x + mvx;
+        ball_shift(A, b, nx - bc.x, (R)0);
+        R ny = bc.y + mvy;
+        ball_shift(A, b, (R)0, ny - bc.y);
+    }
+    RR_SYNC();
+}
+// bounce_balls (RR_TrashyPhysics.py:248-316)
+template <class C> RR_HDN void bounce_balls(Arena<C> &A, int i, int j, int &st) {
+    using R = typename C::Real;
+    R x1 = A.p.bcx[i], y1 = A.p.bcy[i], x2 = A.p.bcx[j], y2 = A.p.bcy[j];
+    if (x1 == x2 && y1 == y2) { st |= ST_SAME_SPOT; return; }
+    R vxx = x2 - x1, vyy = y2 - y1;
+    R d12 = m_sqrt(vxx * vxx + vyy * vyy);
+    R rx = vxx * (R)7 / d12, ry = vyy * (R)7 / d12;
+    R p1x = x1 + rx, p1y = y1 + ry, p2x = x2 - rx, p2y = y2 - ry;
+    const R buffer = (R)1.1;
+    R hx = (p2x - p1x) / (R)2, hy = (p2y - p1y) / (R)2;
+    int m1 = A.bmass[i], m2 = A.bmass[j];
+    R n1x = x1, n1y = y1, n2x = x2, n2y = y2;
+    if (m1 == m2) {
+        n1x = x1 + hx * buffer; n1y = y1 + hy * buffer;
+        n2x = x2 - hx * buffer; n2y = y2 - hy * buffer;
+    } else if (m1 > m2) {
+        n2x = x2 + (p1x - p2x) * buffer; n2y = y2 + (p1y - p2y) * buffer;
+        m2 = m1;
+    } else {
+        n1x = x1 + (p2x - p1x) * buffer; n1y = y1 + (p2y - p1y) * buffer;
+        m1 = m2;
+    }
+    // centre setters are incremental: new centre = c + (n - c)
+    R c1x = x1 + (n1x - x1), c1y = y1 + (n1y - y1), c2x = x2 + (n2x - x2), c2y = y2 + (n2y - y2);
+    R ax = c2x - c1x, ay = c2y - c1y;          // tplVect1to2
+    R bx = ax * (R)-1, by = ay * (R)-1;          // tplVect2to1
+    R d2 = ax * ax + ay * ay;
+    R v1x = A.p.bvx[i], v1y = A.p.bvy[i], v2x = A.p.bvx[j], v2y = A.p.bvy[j];
+    R t1 = div0<R>(ax * v1x + ay * v1y, d2, st);
+    R t2 = div0<R>(bx * v2x + by * v2y, d2, st);
+    R dfx = t1 * ax - t2 * bx, dfy = t1 * ay - t2 * by;
+    v1x -= dfx * (R).995; v1y -= dfy * (R).995;
+    v2x += dfx * (R).995; v2y += dfy * (R).995;
+    R f1x = A.bfx[i], f1y = A.bfy[i], f2x = A.bfx[j], f2y = A.bfy[j];
+    if (f1x > (R)0) v1x = py_max<R>(v1x, f1x); else if (f1x < (R)0) v1x = py_min<R>(v1x, f1x);
+    if (f1y > (R)0) v1y = py_max<R>(v1y, f1y); else if (f1y < (R)0) v1y = py_min<R>(v1y, f1y);
+    if (f2x > (R)0) v2x = py_max<R>(v2x, f2x); else if (f2x < (R)0) v2x = py_min<R>(v2x, f2x);
+    if (f2y > (R)0) v2y = py_max<R>(v2y, f2y); else if (f2y < (R)0) v2y = py_min<R>(v2y, f2y);
+    if (RR_IS_LANE0) {
+        // an unmoved ball gets a zero delta, which leaves its rect bit-identical
+        ball_shift(A, i, n1x - x1, (R)0);
+        ball_shift(A, i, (R)0, n1y - y1);
+        ball_shift(A, j, n2x - x2, (R)0);
+        ball_shift(A, j, (R)0, n2y - y2);
+        A.bmass[i] = m1; A.bmass[j] = m2;
+        A.p.bvx[i] = v1x; A.p.bvy[i] = v1y; A.p.bvx[j] = v2x; A.p.bvy[j] = v2y;
+    }
+    RR_SYNC();
+}
+// bounce_ball_off_wall (RR_TrashyPhysics.py:320-338) -- independent per ball, one lane each
+template <class C> RR_HD void bounce_ball_off_wall_lane(Arena<C> &A, const SimParams<typename C::Real> &sp, int b) {
+    using R = typename C::Real;
+    if (A.p.bl[b] < (R)0) { R v = A.p.bl[b] * (R)-1.1; ball_shift(A, b, v - A.p.bl[b], (R)0); A.p.bvx[b] *= (R)-1 * (R).8; A.bmass[b] = 3; }
+    if (A.p.brt[b] > sp.W) { R v = sp.W - (A.p.brt[b] - sp.W) * (R)1.1; ball_shift(A, b, v - A.p.brt[b], (R)0); A.p.bvx[b] *= (R)-1 * (R).8; A.bmass[b] = 3; }
+    if (A.p.bt[b] <= (R)0) { R v = A.p.bt[b] * (R)-1.1; ball_shift(A, b, (R)0, v - A.p.bt[b]); A.p.bvy[b] *= (R)-1 * (R).8; A.bmass[b] = 3; }
+    if (A.p.bb[b] >= sp.H) { R v = sp.H - (A.p.bb[b] - sp.W) * (R)1.1; ball_shift(A, b, (R)0, v - A.p.bb[b]); A.p.bvy[b] *= (R)-1 * (R).8; A.bmass[b] = 3; }
+}
+// Ball.move (RR_Ball.py:78-105)
+template <class C> RR_HD void ball_move_lane(Arena<C> &A, int b) {
+    using R = typename C::Real;
+    R vx = A.p.bvx[b], vy = A.p.bvy[b], fx = A.bfx[b], fy = A.bfy[b];
+    if (vx >= (R)0 && fx >= (R)0) vx = py_max<R>(vx, fx);
+    else if (vx <= (R)0 && fx <= (R)0) vx = py_min<R>(vx, fx);
+    else vx += fx;
+    if (vy >= (R)0 && fy >= (R)0) vy = py_max<R>(vy, fy);
+    else if (vy <= (R)0 && fy <= (R)0) vy = py_min<R>(vy, fy);
+    else vy += fy;
+    R nl = A.p.bl[b] + vx;
+    ball_shift(A, b, nl - A.p.bl[b], (R)0);
+    R nt = A.p.bt[b] + vy;
+    ball_shift(A, b, (R)0, nt - A.p.bt[b]);
+    vx *= (R).995; vy *= (R).995;
+    if (m_abs(vx) < (R)0.005) vx = (R)0;
+    if (m_abs(vy) < (R)0.005) vy = (R)0;
+    A.p.bvx[b] = vx; A.p.bvy[b] = vy;
+}
+// FloatRect.copy() of a ball rect (MyUtils.py:150-154): centre re-derived through the setters
+template <typename R> RR_HD R ball_copy_c(R c) { return (R)7 + (c - (R)7); }
+// Ball.undo_move (RR_Ball.py:107-113): rect = copy of the (copied) prior-frame rect
+template <class C> RR_HD void ball_undo_lane(Arena<C> &A, int b) {
+    using R = typename C::Real;
+    R dx = A.pfx[b] - (R)7, dy = A.pfy[b] - (R)7;
+    A.p.bcx[b] = (R)7 + dx; A.p.bl[b] = (R)0 + dx; A.p.brt[b] = (R)14 + dx;
+    A.p.bcy[b] = (R)7 + dy; A.p.bt[b] = (R)0 + dy; A.p.bb[b] = (R)14 + dy;
+}
+
+// ------------------------------------------------------------------------------------------------ sub-step pieces (RR_EnvBase.py:303-454)
+template <class C> RR_HD void resolve_bot_collisions(Arena<C> &A, uint32_t &bots_moved, uint32_t &naughty, int &st) {
+    if (C::NPR == 0) return;
+    uint32_t pairs = detect_robot_pairs(A);
+    int attempts = 0;
+    while (pairs) {
+        attempts++;
+        if (attempts > C::NR) { st |= ST_BOT_RESOLVE_FAIL; return; }
+        for (int p = 0; p < C::NPR; p++) {
+            if (!(pairs & (1u << p))) continue;
+            int i, j;
+            pair_of<C>(p, C::NR, i, j);
+            // on_robot_collision -> NaughtyBots (RR_ScoreKeepers.py:123-128)
+            if (A.i.thl[i] != 0 || A.i.thr[i] != 0) naughty |= 1u << i;
+            if (A.i.thl[j] != 0 || A.i.thr[j] != 0) naughty |= 1u << j;
+            uint32_t undo = bots_moved & ((1u << i) | (1u << j));
+            if (!undo) { st |= ST_BOT_STUCK; return; }
+            bots_moved &= ~undo;
+            RR_FOR_LANES(l) {
+                if (l < C::NR && (undo & (1u << l))) robot_undo_lane(A, l);
+            }
+            RR_SYNC();
+        }
+        pairs = detect_robot_pairs(A);
+    }
+}
+template <class C> RR_HD void refresh_inner(Arena<C> &A, const SimParams<typename C::Real> &sp) {
+    RR_FOR_LANES(l) {
+        if (l < C::NR) refresh_inner_lane(A, sp, l);
+    }
+    RR_SYNC();
+}
+template <class C> RR_HD bool resolve_ball_collisions(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t bots_moved, int &st) {
+    bool naughty = true;
+    int count = 0;
+    while (naughty) {
+        count++;
+        if (count > 10) return false;
+        naughty = false;
+        uint64_t bb = detect_ball_pairs(A);
+        for (int p = 0; p < C::NPB; p++) {
+            if (!(bb & (1ull << p))) continue;
+            int i, j;
+            pair_of<C>(p, C::NB, i, j);
+            naughty = true;
+            bounce_balls(A, i, j, st);
+        }
+        uint32_t br = detect_ball_robot(A);
+        for (int p = 0; p < C::NB * C::NR; p++) {
+            if (!(br & (1u << p))) continue;
+            naughty = true;
+            bounce_ball_off_bot(A, p % C::NR, p / C::NR, bots_moved, st);
+        }
+        uint32_t bw = detect_ball_wall(A, sp);
+        if (bw) {
+            naughty = true;
+            RR_FOR_LANES(l) {
+                if (l < C::NB && (bw & (1u << l))) bounce_ball_off_wall_lane(A, sp, l);
+            }
+            RR_SYNC();
+        }
+    }
+    return true;
+}
+template <class C>
+RR_HD void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &balls_moved,
+                                 uint32_t &bots_moved, int &st) {
+    bool naughty = true;
+    int count = 0;
+    const int limit = C::NB + C::NR;
+    while (naughty) {
+        count++;
+        if (count > limit) {
+            if (sp.game_mode) st |= ST_UNDO_WARN;
+            else { st |= ST_UNDO_FAIL; return; }
+        }
+        uint32_t nbots = 0, nballs = 0;
+        uint64_t bb = detect_ball_pairs(A);
+        for (int p = 0; p < C::NPB; p++) {
+            if (!(bb & (1ull << p))) continue;
+            int i, j;
+            pair_of<C>(p, C::NB, i, j);
+            nballs |= (1u << i) | (1u << j);
+        }
+        refresh_inner(A, sp);
+        uint32_t br = detect_ball_robot(A);
+        for (int p = 0; p < C::NB * C::NR; p++) {
+            if (!(br & (1u << p))) continue;
+            nballs |= 1u << (p / C::NR);
+            nbots |= 1u << (p % C::NR);
+        }
+        nballs |= detect_ball_wall(A, sp);
+        naughty = (nbots | nballs) != 0;
+        uint32_t ubots = bots_moved & nbots, uballs = balls_moved & nballs;
+        bots_moved &= ~ubots;
+        balls_moved &= ~uballs;
+        if (ubots | uballs) {
+            RR_FOR_LANES(l) {
+                if (l < C::NR && (ubots & (1u << l))) robot_undo_lane(A, l);
+                if (l < C::NB && (uballs & (1u << l))) ball_undo_lane(A, l);
+            }
+            RR_SYNC();
+        }
+        if (count > limit && naughty && !(ubots | uballs)) { st |= ST_UNDO_FAIL; return; }
+    }
+}
+
+// one of the 12 physics sub-steps ("frame", RR_EnvBase.py:275-287)
+template <class C> RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &naughty, int &st) {
+    using R = typename C::Real;
+    uint32_t bots_moved = (1u << C::NR) - 1, balls_moved = (1u << C::NB) - 1;
+    RR_FOR_LANES(l) { // on_frame_begin (RR_Robot.py:119-120, RR_Ball.py:63-68)
+        if (l < C::NR) {
+            A.ax[l] = A.p.rcx[l]; A.ay[l] = A.p.rcy[l]; A.arot[l] = A.p.rrot[l];
+            for (int k = 0; k < 8; k++) A.arel[l][k] = A.rel[l][k];
+        }
+        if (l < C::NB) {
+            A.bmass[l] = 1; A.bfx[l] = (R)0; A.bfy[l] = (R)0;
+            A.pfx[l] = ball_copy_c<R>(A.p.bcx[l]); A.pfy[l] = ball_copy_c<R>(A.p.bcy[l]);
+        }
+    }
+    RR_SYNC();
+    RR_FOR_LANES(l) { // _move_bots
+        if (l < C::NR) robot_move_lane(A, sp, l);
+    }
+    RR_SYNC();
+    resolve_bot_collisions(A, bots_moved, naughty, st);
+    refresh_inner(A, sp);
+    { // _push_balls (RR_EnvBase.py:335-339): frozen hit list, ball-major order
+        uint32_t br = detect_ball_robot(A);
+        for (int p = 0; p < C::NB * C::NR; p++) {
+            if (!(br & (1u << p))) continue;
+            apply_force_to_ball(A, p % C::NR, p / C::NR, bots_moved, st);
+            bounce_ball_off_bot(A, p % C::NR, p / C::NR, bots_moved, st);
+        }
+    }
+    RR_FOR_LANES(l) { // _roll_balls
+        if (l < C::NB) ball_move_lane(A, l);
+    }
+    RR_SYNC();
+    if (!resolve_ball_collisions(A, sp, bots_moved, st)) undo_naughty_movement(A, sp, balls_moved, bots_moved, st);
+    RR_FOR_LANES(l) { // the ring entry moveCount-1 of a robot whose move survived is this frame's entry
+        if (l < C::NR && (bots_moved & (1u << l))) {
+            A.p.px[l] = A.ax[l]; A.p.py[l] = A.ay[l]; A.p.prot[l] = A.arot[l];
+            for (int k = 0; k < 8; k++) A.prel[l][k] = A.arel[l][k];
+        }
+    }
+    RR_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------------ observation (RR_Observers.py:301-406)
+// lidar: one lane per (ray, rect, side); candidates go to LDS, the wave-uniform tail takes the minima
+template <class C, typename O>
+RR_HD bool observe(Arena<C> &A, const SimParams<typename C::Real> &sp, int team, int ridx, int bidx, O *out, int &st) {
+    using R = typename C::Real;
+    if (ridx < 0) {
+        if (team == 1 && C::NRH == 0) return false;
+        if (team == -1 && C::NRG == 0) return false;
+        ridx = (team == 1) ? 0 : C::NRH;
+    }
+    if (bidx < 0) bidx = 0;
+    constexpr int NT = 3 * 4 * C::NR;
+    RR_FOR_LANES(l) {
+        if (l < NT) {
+            int k = l / (4 * C::NR), q = l % (4 * C::NR), j = q >> 2, s = q & 3, lst = 0;
+            V2<R> a, b; // ray start, end
+            if (k == 0) { // back-mid -> front-mid ; front = RIGHT side, back = LEFT side
+                Seg<R> fr = robot_side(A, ridx, 0), bk = robot_side(A, ridx, 2);
+                b = { (fr.a.x + fr.b.x) / (R)2, (fr.a.y + fr.b.y) / (R)2 };
+                a = { (bk.a.x + bk.b.x) / (R)2, (bk.a.y + bk.b.y) / (R)2 };
+            } else if (k == 1) { a = robot_corner(A, ridx, BL); b = robot_corner(A, ridx, TR); }
+            else { a = robot_corner(A, ridx, TL); b = robot_corner(A, ridx, BR); }
+            Seg<R> side;
+            if (j < C::NR - 1) {
+                side = robot_side(A, j < ridx ? j : j + 1, s);
+            } else { // rect_walls = FloatRect(0, W, 0, H) (RR_EnvBase.py:74)
+                R hx = sp.W / (R)2, hy = sp.H / (R)2;
+                const R wx[4] = { hx + -hx, hx + hx, hx + -hx, hx + hx }, wy[4] = { hy + -hy, hy + -hy, hy + hy, hy + hy };
+                side = { { wx[side_a(s)], wy[side_a(s)] }, { wx[side_b(s)], wy[side_b(s)] } };
+            }
+            Seg<R> ray = { a, b };
+            V2<R> I = line_intersection<R>(side, ray, lst);
+            R de = dist<R>(I, b), ds = dist<R>(I, a);
+            A.lf[l] = (de <= ds) ? de : inf_<R>();
+            A.lb[l] = (ds <= de) ? ds : inf_<R>();
+        }
+    }
+    RR_SYNC();
+    R lid[6]; // front, back per ray
+    for (int k = 0; k < 3; k++) {
+        R f = inf_<R>(), b = inf_<R>();
+        for (int q = 0; q < 4 * C::NR; q++) {
+            R vf = A.lf[k * 4 * C::NR + q], vb = A.lb[k * 4 * C::NR + q];
+            if (vf < f) f = vf;
+            if (vb < b) b = vb;
+        }
+        lid[2 * k] = py_min<R>(f, (R)150);
+        lid[2 * k + 1] = py_min<R>(b, (R)150);
+    }
+    V2<R> rc = { A.p.rcx[ridx], A.p.rcy[ridx] }, bc = { A.p.bcx[bidx], A.p.bcy[bidx] };
+    V2<R> good = { sp.W, sp.H }, bad = { (R)0, (R)0 };
+    R ball_angle = angle_degrees<R>(rc, bc, st);
+    R ball_dist = py_min<R>(dist<R>(rc, bc), (R)150);
+    R goal_angle = angle_degrees<R>(rc, good, st);
+    R bot_angle = A.p.rrot[ridx];
+    R dbad = dist<R>(rc, bad), dgood = dist<R>(rc, good);
+    R goal_dist = (dgood <= dbad) ? py_min<R>(dgood, (R)390) : (R)-1 * py_min<R>(dbad, (R)390);
+    bool ball_neg = bidx >= C::NBP;
+    if ((team == 1 && ball_neg) || (team == -1 && !ball_neg)) {
+        goal_dist *= (R)-1;
+        ball_angle = py_mod<R>(ball_angle + (R)180, (R)360);
+        goal_angle = py_mod<R>(goal_angle + (R)180, (R)360);
+        bot_angle = py_mod<R>(bot_angle + (R)180, (R)360);
+    }
+    if (RR_IS_LANE0) {
+        out[0] = (O)bot_angle; out[1] = (O)ball_angle; out[2] = (O)ball_dist; out[3] = (O)goal_angle; out[4] = (O)goal_dist;
+        // lidar_front, front_l, front_r, back, back_l, back_r ; ray1 = (front_l, back_r), ray2 = (front_r, back_l)
+        out[5] = (O)lid[0]; out[6] = (O)lid[2]; out[7] = (O)lid[4]; out[8] = (O)lid[1]; out[9] = (O)lid[5]; out[10] = (O)lid[3];
+    }
+    RR_SYNC();
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ derived data, clean poses
+// scratch that is a pure function of the persistent record: corner offsets of every pose in it
+template <class C> RR_HD void derive(Arena<C> &A, const SimParams<typename C::Real> &sp) {
+    using R = typename C::Real;
+    RR_FOR_LANES(l) {
+        if (l < C::NR) {
+            corners_for<R>(A.p.rrot[l], (R)10, (R)20, sp.rob_cdist, A.rel[l]);
+            if (!is_nan(A.p.px[l]))
+                corners_for<R>(py_mod<R>(A.p.prot[l] + (R)720, (R)360), (R)10, (R)20, sp.rob_cdist, A.prel[l]);
+            A.irot[l] = (R)NAN;
+            refresh_inner_lane(A, sp, l);
+        }
+    }
+    RR_SYNC();
+}
+// "clean" robot pose: centre exactly (x,y), edges re-derived like the rotation setter, no history
+template <class C> RR_HD void robot_set_clean_lane(Arena<C> &A, const SimParams<typename C::Real> &sp, int r,
+                                                   typename C::Real x, typename C::Real y, typename C::Real rot) {
+    using R = typename C::Real;
+    FR<R> f;
+    f.cx = x; f.cy = y; f.rot = py_mod<R>(rot + (R)720, (R)360);
+    corners_for<R>(f.rot, (R)10, (R)20, sp.rob_cdist, f.rel);
+    fr_edges_from_rel<R>(f);
+    store_robot(A, r, f);
+    A.p.px[r] = (R)NAN; A.p.py[r] = (R)NAN; A.p.prot[r] = (R)NAN;
+    A.i.mc[r] = 0; A.i.thl[r] = 0; A.i.thr[r] = 0;
+    A.irot[r] = (R)NAN;
+}
+template <class C> RR_HD void ball_set_clean_lane(Arena<C> &A, int b, typename C::Real x, typename C::Real y,
+                                                  typename C::Real vx, typename C::Real vy) {
+    using R = typename C::Real;
+    A.p.bcx[b] = x; A.p.bcy[b] = y;
+    A.p.bl[b] = x - (R)7; A.p.brt[b] = x + (R)7; A.p.bt[b] = y - (R)7; A.p.bb[b] = y + (R)7;
+    A.p.bvx[b] = vx; A.p.bvy[b] = vy;
+}
+
+// ------------------------------------------------------------------------------------------------ reset (RR_EnvBase.py:155-216)
+// Counter-based RNG: Philox4x32-10, key = seed, counter = (global arena id, episode, draw/4).
+RR_HD void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+struct Rng { uint64_t seed, arena, episode; uint32_t draw; };
+RR_HD uint32_t rng_u32(Rng &g) {
+    uint32_t c[4] = { (uint32_t)g.arena, (uint32_t)(g.arena >> 32), (uint32_t)g.episode, g.draw >> 2 };
+    philox4x32(c, (uint32_t)g.seed, (uint32_t)(g.seed >> 32));
+    uint32_t v = c[g.draw & 3];
+    g.draw++;
+    return v;
+}
+RR_HD long rng_randint(Rng &g, long a, long b) {
+    uint64_t n = (uint64_t)(b - a + 1);
+    return a + (long)(((uint64_t)rng_u32(g) * n) >> 32);
+}
+struct IRect { long l, t, w, h; };
+template <typename R> RR_HD IRect irect(R l, R t, R r, R b) { // pygame.Rect(l, t, r-l, b-t): C-int truncation
+    IRect q = { (long)l, (long)t, (long)(r - l), (long)(b - t) };
+    return q;
+}
+RR_HD bool icollide(IRect a, IRect b) { return a.l < b.l + b.w && a.t < b.t + b.h && a.l + a.w > b.l && a.t + a.h > b.t; }
+template <class C> RR_HD IRect robot_irect(const Arena<C> &A, int r) { return irect(A.p.rl[r], A.p.rt[r], A.p.rrt[r], A.p.rb[r]); }
+template <class C> RR_HD IRect ball_irect(const Arena<C> &A, int b) { return irect(A.p.bl[b], A.p.bt[b], A.p.brt[b], A.p.bb[b]); }
+
+template <class C>
+RR_HDN void reset_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64_t arena_gid, uint64_t episode, int &st) {
+    using R = typename C::Real;
+    Rng g = { sp.seed, arena_gid, episode, 0 };
+    const int MAX_TRY = 4096;
+    // sprite.on_reset: robots re-init in place at rot 90 / 270, balls stop (RR_Robot.py:87-88, RR_Ball.py:70-76)
+    RR_FOR_LANES(l) {
+        if (l < C::NR) robot_set_clean_lane(A, sp, l, A.p.rcx[l], A.p.rcy[l], l < C::NRH ? (R)90 : (R)-90);
+        if (l < C::NB) { A.p.bvx[l] = (R)0; A.p.bvy[l] = (R)0; }
+        if (l == 0) { A.i.step = 0; A.i.episode = (int32_t)episode; A.i.ep_len = 0; A.p.acc[0] = (R)0; A.p.acc[1] = (R)0; }
+    }
+    RR_SYNC();
+    // robots not yet placed still block at their old pose (RR_EnvBase.py:157-158 writes sprite attrs only)
+    for (int i = 0; i < C::NR; i++) {
+        for (int t = 0;; t++) {
+            long x = rng_randint(g, 40 * 2, (long)sp.W - 40 * 2);
+            long y = rng_randint(g, 20 * 2, (long)sp.H - 20 * 2);
+            long rot = rng_randint(g, 0, 360);
+            RR_FOR_LANES(l) {
+                if (l == 0) robot_set_clean_lane(A, sp, i, (R)x, (R)y, (R)rot);
+            }
+            RR_SYNC();
+            IRect me = robot_irect(A, i);
+            int hits = 0;
+            for (int j = 0; j < C::NR; j++) hits += icollide(me, robot_irect(A, j)) ? 1 : 0;
+            if (hits <= 1) break;
+            if (t >= MAX_TRY) { st |= ST_RESET_GAVE_UP; break; }
+        }
+    }
+    RR_FOR_LANES(l) {
+        if (l < C::NB) ball_set_clean_lane(A, l, (R)-1000, (R)-1000, (R)0, (R)0); // RR_EnvBase.py:183-184
+    }
+    RR_SYNC();
+    IRect goal_h = { (long)(sp.W - (R)240), (long)(sp.H - (R)240), 240, 240 }, goal_g = { 0, 0, 240, 240 }; // RR_Goal.py:30-35
+    for (int i = 0; i < C::NB; i++) {
+        for (int t = 0;; t++) {
+            long x = rng_randint(g, 40, (long)sp.W - 40);
+            long y = rng_randint(g, 40, (long)sp.H - 40);
+            RR_FOR_LANES(l) {
+                if (l == 0) ball_set_clean_lane(A, i, (R)x, (R)y, (R)0, (R)0);
+            }
+            RR_SYNC();
+            IRect me = ball_irect(A, i);
+            int hits = (icollide(me, goal_h) ? 1 : 0) + (icollide(me, goal_g) ? 1 : 0);
+            for (int j = 0; j < C::NR; j++) hits += icollide(me, robot_irect(A, j)) ? 1 : 0;
+            for (int j = 0; j < C::NB; j++) hits += icollide(me, ball_irect(A, j)) ? 1 : 0;
+            if (hits <= 1) break;
+            if (t >= MAX_TRY) { st |= ST_RESET_GAVE_UP; break; }
+        }
+    }
+    derive(A, sp);
+}
+
+// ------------------------------------------------------------------------------------------------ whole step (RR_EnvBase.py:260-297)
+template <typename R> RR_HD bool is_done(int step, const SimParams<R> &sp) {
+    return sp.time_limit ? (step >= sp.game_len) : (step > sp.game_len); // TimeLimit wrapper vs raw :555-559
+}
+template <typename O> struct StepOut {
+    O *obs, *obs_g, *reward, *reward_g;
+    uint8_t *done;
+    int32_t *status;
+};
+
+// actions: this arena's na discrete actions (thrust == nullptr) or 2*na thrust floats
+template <class C, typename O>
+RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64_t arena_gid, const int32_t *actions,
+                      const float *thrust, int na, const StepOut<O> &o) {
+    using R = typename C::Real;
+    int st = 0;
+    // raw mode raises when stepping a finished game (:261-262); with auto_reset the call resets instead
+    if (sp.time_limit ? (A.i.step >= sp.game_len) : (A.i.step > sp.game_len)) {
+        if (sp.auto_reset) {
+            reset_arena(A, sp, arena_gid, (uint64_t)(uint32_t)(A.i.episode + 1), st);
+            st |= ST_WAS_RESET;
+            observe<C, O>(A, sp, 1, -1, -1, o.obs, st);
+            if (o.obs_g) {
+                if (!observe<C, O>(A, sp, -1, -1, -1, o.obs_g, st)) {
+                    RR_FOR_LANES(l) { if (l < 11) o.obs_g[l] = (O)NAN; }
+                }
+            }
+            if (RR_IS_LANE0) {
+                *o.reward = (O)0; *o.done = 0;
+                if (o.reward_g) *o.reward_g = (O)0;
+                if (o.status) *o.status = st;
+            }
+            return;
+        }
+        st |= ST_STEP_AFTER_DONE;
+        observe<C, O>(A, sp, 1, -1, -1, o.obs, st);
+        if (o.obs_g) {
+            if (!observe<C, O>(A, sp, -1, -1, -1, o.obs_g, st)) {
+                RR_FOR_LANES(l) { if (l < 11) o.obs_g[l] = (O)NAN; }
+            }
+        }
+        if (RR_IS_LANE0) {
+            *o.reward = (O)0; *o.done = 1;
+            if (o.reward_g) *o.reward_g = (O)0;
+            if (o.status) *o.status = st;
+        }
+        return;
+    }
+    // ---- on_step_begin (:264-265; sprites, then the score keepers RR_ScoreKeepers.py:30-33,119-121,145-147)
+    R dist_sum0 = (R)0;
+    {
+        V2<R> o0 = { (R)0, (R)0 };
+        for (int b = 0; b < C::NBP; b++) { V2<R> c = { A.p.bcx[b], A.p.bcy[b] }; dist_sum0 = dist_sum0 + dist<R>(o0, c); }
+    }
+    RR_FOR_LANES(l) {
+        if (l < C::NR) {
+            A.psx[l] = A.p.rcx[l]; A.psy[l] = A.p.rcy[l];
+            if (l < na) { // set_thrust (RR_Robot.py:100-102)
+                if (thrust) {
+                    A.i.thl[l] = (int)m_rint(thrust[2 * l]); A.i.thr[l] = (int)m_rint(thrust[2 * l + 1]);
+                } else {
+                    int a = actions[l];
+                    if (a >= 0 && a <= 7) { // Direction table, RR_EnvBase.py:593-602
+                        A.i.thl[l] = (a == 0 || a == 3 || a == 5) ? 1 : (a == 4 || a == 7) ? 0 : -1;
+                        A.i.thr[l] = (a == 0 || a == 2 || a == 4) ? 1 : (a == 5 || a == 6) ? 0 : -1;
+                    }
+                }
+            }
+        }
+        if (l == 0) A.i.step += 1;
+    }
+    if (!thrust) for (int q = 0; q < na && q < C::NR; q++) { int a = actions[q]; if (a < 0 || a > 7) st |= ST_BAD_ACTION; }
+    RR_SYNC();
+    uint32_t naughty = 0;
+    for (int f = 0; f < 12; f++) substep(A, sp, naughty, st); // MOVES_PER_FRAME
+    // ---- on_step_end: NaughtyBots, ChasePosBall, PushPosBallsToGoal (SURVEY 3.1 accumulation order)
+    R rew_h = (R)0, rew_g = (R)0;
+    for (int r = 0; r < C::NR; r++) if (naughty & (1u << r)) { if (r < C::NRH) rew_h -= (R).005; else rew_g -= (R).005; }
+    for (int r = 0; r < C::NR; r++) {
+        V2<R> rc = { A.p.rcx[r], A.p.rcy[r] }, pc = { A.psx[r], A.psy[r] };
+        for (int b = 0; b < C::NBP; b++) {
+            V2<R> bc = { A.p.bcx[b], A.p.bcy[b] };
+            R now = dist<R>(rc, bc), prior = dist<R>(pc, bc);
+            if (r < C::NRH) rew_h += (prior - now) * sp.mult_robot; else rew_g += (prior - now) * sp.mult_robot;
+        }
+    }
+    {
+        R s1 = (R)0;
+        V2<R> o0 = { (R)0, (R)0 };
+        for (int b = 0; b < C::NBP; b++) { V2<R> c = { A.p.bcx[b], A.p.bcy[b] }; s1 = s1 + dist<R>(o0, c); }
+        R delta = s1 - dist_sum0;
+        rew_h += delta * sp.mult_ball;
+        rew_g -= delta * sp.mult_ball;
+    }
+    const int step_now = A.i.step;
+    const bool done = is_done<R>(step_now, sp);
+    observe<C, O>(A, sp, 1, -1, -1, o.obs, st);
+    if (o.obs_g) {
+        if (!observe<C, O>(A, sp, -1, -1, -1, o.obs_g, st)) {
+            RR_FOR_LANES(l) { if (l < 11) o.obs_g[l] = (O)NAN; }
+        }
+    }
+    if (RR_IS_LANE0) {
+        *o.reward = (O)rew_h; *o.done = done ? 1 : 0;
+        if (o.reward_g) *o.reward_g = (O)rew_g;
+        if (o.status) *o.status = st;
+        // episode bookkeeping for logging (the caller sums `score` the same way, Training_DQN_pytorch.py:345-346)
+        A.p.acc[0] += rew_h; A.p.acc[1] += rew_g; A.i.ep_len += 1;
+        if (done) { A.p.acc[2] = A.p.acc[0]; A.p.acc[3] = A.p.acc[1]; A.i.last_len = A.i.ep_len; A.i.ep_count += 1; }
+    }
+    RR_SYNC();
+}
+
+} // namespace rr

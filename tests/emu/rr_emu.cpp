@@ -1,0 +1,136 @@
+// rr_emu.cpp -- host-emulated wave: compiles roborugby_amd/csrc/rr_sim.hpp with g++ where each
+// "lane-parallel" phase is a 64-iteration loop.  TEST HARNESS ONLY: it lets the CPU test-suite
+// check the kernel's phase logic (lane->task maps, ballot masks, response ordering) against the
+// oracle without a GPU.  The product library never links or loads this.
+#include "../../roborugby_amd/csrc/rr_sim.hpp"
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+using namespace rr;
+
+template <class C> struct Emu {
+    Arena<C> A;
+    SimParams<typename C::Real> sp;
+};
+
+template <typename R> static void fill_params(SimParams<R> &sp, double W, double H, int game_len, int game_mode,
+                                              int time_limit, int auto_reset, uint64_t seed) {
+    sp.W = (R)W; sp.H = (R)H;
+    double mb = 200000.0 / std::pow(W * W + H * H, .5);
+    sp.mult_ball = (R)mb; sp.mult_robot = (R)(mb / 100);
+    sp.rob_cdist = (R)std::pow(10.0 * 10.0 + 20.0 * 20.0, .5);
+    double hr = 7 * std::pow(2.0, .5) / 2;
+    sp.inner_h = (R)hr;
+    sp.inner_cdist = (R)std::pow(hr * hr + hr * hr, .5);
+    sp.game_len = game_len; sp.game_mode = game_mode; sp.time_limit = time_limit; sp.auto_reset = auto_reset;
+    sp.seed = seed; sp.arena_offset = 0;
+}
+
+template <class C> static void set_state(Emu<C> *e, const double *robots, const int32_t *ri, const double *balls, int step) {
+    using R = typename C::Real;
+    Arena<C> &A = e->A;
+    for (int r = 0; r < C::NR; r++) {
+        const double *q = robots + 10 * r;
+        A.p.rcx[r] = (R)q[0]; A.p.rcy[r] = (R)q[1]; A.p.rl[r] = (R)q[2]; A.p.rrt[r] = (R)q[3]; A.p.rt[r] = (R)q[4];
+        A.p.rb[r] = (R)q[5]; A.p.rrot[r] = (R)q[6]; A.p.px[r] = (R)q[7]; A.p.py[r] = (R)q[8]; A.p.prot[r] = (R)q[9];
+        A.i.mc[r] = ri[3 * r]; A.i.thl[r] = ri[3 * r + 1]; A.i.thr[r] = ri[3 * r + 2];
+    }
+    for (int b = 0; b < C::NB; b++) {
+        const double *q = balls + 8 * b;
+        A.p.bcx[b] = (R)q[0]; A.p.bcy[b] = (R)q[1]; A.p.bl[b] = (R)q[2]; A.p.brt[b] = (R)q[3]; A.p.bt[b] = (R)q[4];
+        A.p.bb[b] = (R)q[5]; A.p.bvx[b] = (R)q[6]; A.p.bvy[b] = (R)q[7];
+    }
+    A.i.step = step;
+    derive(A, e->sp);
+}
+template <class C> static void get_state(Emu<C> *e, double *robots, int32_t *ri, double *balls, int32_t *step) {
+    Arena<C> &A = e->A;
+    for (int r = 0; r < C::NR; r++) {
+        double *q = robots + 10 * r;
+        q[0] = A.p.rcx[r]; q[1] = A.p.rcy[r]; q[2] = A.p.rl[r]; q[3] = A.p.rrt[r]; q[4] = A.p.rt[r]; q[5] = A.p.rb[r];
+        q[6] = A.p.rrot[r]; q[7] = A.p.px[r]; q[8] = A.p.py[r]; q[9] = A.p.prot[r];
+        ri[3 * r] = A.i.mc[r]; ri[3 * r + 1] = A.i.thl[r]; ri[3 * r + 2] = A.i.thr[r];
+    }
+    for (int b = 0; b < C::NB; b++) {
+        double *q = balls + 8 * b;
+        q[0] = A.p.bcx[b]; q[1] = A.p.bcy[b]; q[2] = A.p.bl[b]; q[3] = A.p.brt[b]; q[4] = A.p.bt[b]; q[5] = A.p.bb[b];
+        q[6] = A.p.bvx[b]; q[7] = A.p.bvy[b];
+    }
+    *step = A.i.step;
+}
+
+typedef Cfg<1, 0, 1, 0, double> CT64;
+typedef Cfg<2, 2, 4, 4, double> CG64;
+typedef Cfg<1, 0, 1, 0, float> CT32;
+typedef Cfg<2, 2, 4, 4, float> CG32;
+
+struct Handle { int kind; void *p; };
+
+#define DISPATCH(h, ...)                                                   \
+    switch ((h)->kind) {                                                   \
+    case 0: { auto *e = (Emu<CT64> *)(h)->p; typedef CT64 CC; __VA_ARGS__; } break; \
+    case 1: { auto *e = (Emu<CG64> *)(h)->p; typedef CG64 CC; __VA_ARGS__; } break; \
+    case 2: { auto *e = (Emu<CT32> *)(h)->p; typedef CT32 CC; __VA_ARGS__; } break; \
+    case 3: { auto *e = (Emu<CG32> *)(h)->p; typedef CG32 CC; __VA_ARGS__; } break; \
+    }
+
+extern "C" {
+// preset: 0 = T, 1 = G ; f32: 0/1
+Handle *emu_create(int preset, int f32, double W, double H, int game_len, int game_mode, int time_limit, int auto_reset,
+                   uint64_t seed) {
+    Handle *h = new Handle;
+    h->kind = preset + 2 * f32;
+    switch (h->kind) {
+    case 0: h->p = calloc(1, sizeof(Emu<CT64>)); break;
+    case 1: h->p = calloc(1, sizeof(Emu<CG64>)); break;
+    case 2: h->p = calloc(1, sizeof(Emu<CT32>)); break;
+    default: h->p = calloc(1, sizeof(Emu<CG32>)); break;
+    }
+    DISPATCH(h, fill_params(e->sp, W, H, game_len, game_mode, time_limit, auto_reset, seed); (void)sizeof(CC);
+             for (int r = 0; r < CC::NR; r++) robot_set_clean_lane(e->A, e->sp, r, (typename CC::Real)0, (typename CC::Real)0,
+                                                                   r < CC::NRH ? (typename CC::Real)90 : (typename CC::Real)-90);
+             for (int b = 0; b < CC::NB; b++) ball_set_clean_lane(e->A, b, (typename CC::Real)0, (typename CC::Real)0,
+                                                                  (typename CC::Real)0, (typename CC::Real)0);
+             derive(e->A, e->sp));
+    return h;
+}
+void emu_destroy(Handle *h) { free(h->p); delete h; }
+void emu_set_state(Handle *h, const double *robots, const int32_t *ri, const double *balls, int step) {
+    DISPATCH(h, set_state<CC>(e, robots, ri, balls, step));
+}
+void emu_get_state(Handle *h, double *robots, int32_t *ri, double *balls, int32_t *step) {
+    DISPATCH(h, get_state<CC>(e, robots, ri, balls, step));
+}
+void emu_set_poses(Handle *h, const double *rxyr, const double *bxyv) {
+    DISPATCH(h, for (int r = 0; r < CC::NR; r++) robot_set_clean_lane(e->A, e->sp, r, (typename CC::Real)rxyr[3 * r],
+                                                                   (typename CC::Real)rxyr[3 * r + 1], (typename CC::Real)rxyr[3 * r + 2]);
+             for (int b = 0; b < CC::NB; b++) ball_set_clean_lane(e->A, b, (typename CC::Real)bxyv[4 * b], (typename CC::Real)bxyv[4 * b + 1],
+                                                                  (typename CC::Real)bxyv[4 * b + 2], (typename CC::Real)bxyv[4 * b + 3]);
+             e->A.i.step = 0; derive(e->A, e->sp));
+}
+int emu_step(Handle *h, const int32_t *actions, int na, double *obs, double *obs_g, double *reward, double *reward_g,
+             uint8_t *done) {
+    int32_t status = 0;
+    StepOut<double> o = { obs, obs_g, reward, reward_g, done, &status };
+    DISPATCH(h, step_arena<CC, double>(e->A, e->sp, 0, actions, nullptr, na, o));
+    return status;
+}
+int emu_step_thrust(Handle *h, const float *thrust, int nk, double *obs, double *obs_g, double *reward, double *reward_g,
+                    uint8_t *done) {
+    int32_t status = 0;
+    StepOut<double> o = { obs, obs_g, reward, reward_g, done, &status };
+    DISPATCH(h, step_arena<CC, double>(e->A, e->sp, 0, nullptr, thrust, nk, o));
+    return status;
+}
+int emu_observe(Handle *h, int team, int ridx, int bidx, double *obs) {
+    int st = 0, ok = 0;
+    DISPATCH(h, ok = observe<CC, double>(e->A, e->sp, team, ridx, bidx, obs, st) ? 1 : 0);
+    return ok;
+}
+int emu_reset(Handle *h, uint64_t arena, uint64_t episode) {
+    int st = 0;
+    DISPATCH(h, reset_arena(e->A, e->sp, arena, episode, st));
+    return st;
+}
+}

@@ -1,0 +1,108 @@
+"""ctypes binding of the host-emulated wave (tests/emu/rr_emu.cpp) -- test harness only.
+
+The emulation compiles the kernel's own source (roborugby_amd/csrc/rr_sim.hpp) with g++, running every
+lane-parallel phase as a 64-iteration loop.  It checks phase logic on CPU; it is never a product path."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import oracle_lib as ol
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "emu", "librr_emu.so")
+SRC = [os.path.join(HERE, "emu", "rr_emu.cpp"), os.path.join(ol.REPO, "roborugby_amd", "csrc", "rr_sim.hpp")]
+
+
+def build():
+    if not os.path.exists(SO) or any(os.path.getmtime(SO) < os.path.getmtime(s) for s in SRC):
+        subprocess.check_call(["g++", "-O2", "-fPIC", "-ffp-contract=off", "-std=c++17", "-shared", "-o", SO, SRC[0]])
+    return SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        dp, ip, u8p, fp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.POINTER(C.c_float)
+        L.emu_create.restype = C.c_void_p
+        L.emu_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]
+        L.emu_destroy.argtypes = [C.c_void_p]
+        L.emu_set_state.argtypes = [C.c_void_p, dp, ip, dp, C.c_int]
+        L.emu_get_state.argtypes = [C.c_void_p, dp, ip, dp, ip]
+        L.emu_set_poses.argtypes = [C.c_void_p, dp, dp]
+        L.emu_step.argtypes = [C.c_void_p, ip, C.c_int, dp, dp, dp, dp, u8p]
+        L.emu_step_thrust.argtypes = [C.c_void_p, fp, C.c_int, dp, dp, dp, dp, u8p]
+        L.emu_observe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, dp]
+        L.emu_reset.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class EmuEnv:
+    def __init__(self, preset="T", f32=False, time_limit=0, auto_reset=0, seed=0):
+        cfg = ol.PRESETS[preset]
+        self.cfg = cfg
+        self.nr = cfg["nr_h"] + cfg["nr_g"]
+        self.nb = cfg["nb_p"] + cfg["nb_n"]
+        self.h = lib().emu_create(0 if preset == "T" else 1, int(f32), cfg["W"], cfg["H"], cfg["game_len"],
+                                  cfg["game_mode"], time_limit, auto_reset, seed)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().emu_destroy(self.h)
+            self.h = None
+
+    def set_state(self, robots, robots_i, balls, step=0):
+        r = np.ascontiguousarray(robots, np.float64)
+        ri = np.ascontiguousarray(robots_i, np.int32)
+        b = np.ascontiguousarray(balls, np.float64)
+        lib().emu_set_state(self.h, _dp(r), _ip(ri), _dp(b), int(step))
+
+    def get_state(self):
+        r = np.zeros((self.nr, 10))
+        ri = np.zeros((self.nr, 3), np.int32)
+        b = np.zeros((self.nb, 8))
+        st = np.zeros(1, np.int32)
+        lib().emu_get_state(self.h, _dp(r), _ip(ri), _dp(b), _ip(st))
+        return dict(robots=r, robots_i=ri, balls=b, step=int(st[0]))
+
+    def set_poses(self, rxyr, bxyv):
+        r = np.ascontiguousarray(rxyr, np.float64)
+        b = np.ascontiguousarray(bxyv, np.float64)
+        lib().emu_set_poses(self.h, _dp(r), _dp(b))
+
+    def step(self, actions):
+        a = np.ascontiguousarray(np.asarray(actions).reshape(-1), np.int32)
+        obs, obs_g, rew, rew_g = np.zeros(11), np.zeros(11), np.zeros(1), np.zeros(1)
+        done = np.zeros(1, np.uint8)
+        st = lib().emu_step(self.h, _ip(a), len(a), _dp(obs), _dp(obs_g), _dp(rew), _dp(rew_g),
+                            done.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return dict(obs=obs, obs_g=obs_g, reward=float(rew[0]), reward_g=float(rew_g[0]), done=bool(done[0]), status=int(st))
+
+    def step_thrust(self, thrust):
+        t = np.ascontiguousarray(np.asarray(thrust, np.float32).reshape(-1))
+        obs, obs_g, rew, rew_g = np.zeros(11), np.zeros(11), np.zeros(1), np.zeros(1)
+        done = np.zeros(1, np.uint8)
+        st = lib().emu_step_thrust(self.h, t.ctypes.data_as(C.POINTER(C.c_float)), len(t) // 2, _dp(obs), _dp(obs_g),
+                                   _dp(rew), _dp(rew_g), done.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return dict(obs=obs, obs_g=obs_g, reward=float(rew[0]), reward_g=float(rew_g[0]), done=bool(done[0]), status=int(st))
+
+    def observe(self, team=1, robot=-1, ball=-1):
+        o = np.zeros(11)
+        return o if lib().emu_observe(self.h, team, robot, ball, _dp(o)) else None
+
+    def reset(self, arena, episode):
+        return lib().emu_reset(self.h, int(arena), int(episode))
