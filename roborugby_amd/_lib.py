@@ -1,0 +1,70 @@
+"""ctypes binding of the C-ABI in include/roborugby_amd.h.
+
+There is NO CPU fallback: if the HIP library is missing or cannot be loaded this module raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libroborugby_amd.so")
+
+
+class RRConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("num_envs", C.c_int32),
+        ("nr_happy", C.c_int32), ("nr_grumpy", C.c_int32), ("nb_pos", C.c_int32), ("nb_neg", C.c_int32),
+        ("arena_w", C.c_double), ("arena_h", C.c_double),
+        ("game_len_steps", C.c_int32), ("game_mode", C.c_int32), ("time_limit", C.c_int32), ("auto_reset", C.c_int32),
+        ("dtype", C.c_int32), ("device", C.c_int32),
+        ("seed", C.c_uint64), ("arena_offset", C.c_uint64),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/roborugby_amd.h declares
+_vp = C.c_void_p
+SYMBOLS = {
+    "rr_abi_version": (C.c_int, []),
+    "rr_last_error": (C.c_char_p, []),
+    "rr_create": (C.c_int, [C.POINTER(RRConfig), C.POINTER(_vp)]),
+    "rr_destroy": (C.c_int, [_vp]),
+    "rr_reset": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "rr_step": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rr_step_f64": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rr_step_thrust": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rr_observe": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
+    "rr_observe_f64": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
+    "rr_set_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "rr_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "rr_set_poses": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "rr_episode_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "rr_state_bytes_per_env": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libroborugby_amd.so (built by roborugby_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the gfx950 library first (python -m roborugby_amd.build). "
+            "roborugby_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class RRError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().rr_last_error()
+        raise RRError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")

