@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- random-policy rollout throughput of the batched RoboRugby step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path (GameEnv.step: 12 physics sub-steps + reward + observation + done,
+reference RR_EnvBase.py:260-297) over one batch of 65,536 arenas per GPU.  Metric = BASELINE.json's
+env-steps/s (whole job).  Inputs (state, actions) are resident in HBM when the timed region starts.
+Rank 0 prints ONE JSON line, with `roofline` (dominant kernel vs the HBM roof) and `cpu_baseline`
+(the CPU oracle timed on this box's host cores on a bounded sample -- a reported baseline, not the target).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import threading
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--arenas", type=int, default=65536, help="arenas per GPU (weak scaling)")
+    ap.add_argument("--preset", default="G", choices=["G", "T"],
+                    help="G = constants as checked in (2+2 robots, 4+4 balls, 800x800); T = DQN training preset")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--policy", default="random", choices=["random", "chase"])
+    ap.add_argument("--log-interval", type=int, default=25, help="steps between RCCL all-gathers of episode returns")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def maybe_relaunch(args):
+    """`python bench.py --gpus 4` without a launcher: start torch.distributed.run as a child (before any GPU use)."""
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29511"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+
+def cpu_baseline(preset, seconds):
+    """CPU oracle (oracle/rr_oracle.c: the fp64 restatement pinned bit-exact to the reference) stepping the same
+    kind of workload -- random actions from reset -- on this box's host cores, one thread per core."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle_lib as ol
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    t0 = time.perf_counter()
+    n_cal, _ = ol.rollout(preset, 2, 40, seed=99)
+    rate1 = n_cal / max(time.perf_counter() - t0, 1e-6)
+    steps = 100
+    arenas = max(1, int(rate1 * seconds / steps))
+    done = [0] * cores
+
+    def work(i):
+        done[i], _ = ol.rollout(preset, arenas, steps, seed=1000 + i)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {"value": sum(done) / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} threads x {arenas} arenas x {steps} steps of preset {preset}, random actions from "
+                      f"reset, fp64 C oracle (bit-exact to the Python reference on tests/golden); {dt:.1f} s wall",
+            "single_core_value": rate1}
+
+
+def chase_actions(obs, noise, gen):
+    """turn toward ball_angle, else forward; `noise` fraction random (SURVEY section 8d contact-rich stream)."""
+    import torch
+    d = (obs[:, 1] - obs[:, 0] + 540.0) % 360.0 - 180.0
+    a = torch.where(d.abs() < 8, 0, torch.where(d > 0, 2, 3)).to(torch.int32)
+    r = torch.randint(0, 8, a.shape, generator=gen, device=a.device, dtype=torch.int32)
+    m = torch.rand(a.shape, generator=gen, device=a.device) < noise
+    return torch.where(m, r, a)
+
+
+def main():
+    args = parse()
+    maybe_relaunch(args)
+    import torch
+    import roborugby_amd as rr
+    from roborugby_amd import dist as rrd
+
+    rank, local_rank, world = rrd.init_process_group()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    n = args.arenas
+    env = rr.BatchedRoboRugbyEnv(n, preset=args.preset, device=dev, seed=0, time_limit=True, auto_reset=True,
+                                 dtype=args.dtype, arena_offset=rrd.shard_offset(rank, n))
+    p = env.preset
+    na = p.nr
+    obs = env.reset()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    K, W = args.steps, args.warmup
+    # action stream resident in HBM before the clock starts (the policy is not the thing measured)
+    if args.policy == "random":
+        acts = torch.randint(0, 8, (K + W, n, na), generator=gen, device=dev, dtype=torch.int32)
+    out = (torch.empty(n, 11, device=dev), torch.empty(n, device=dev), torch.empty(n, dtype=torch.uint8, device=dev),
+           torch.empty(n, 11, device=dev) if p.nr_grumpy else None, torch.empty(n, device=dev),
+           torch.empty(n, dtype=torch.int32, device=dev))
+
+    def one_step(i):
+        if args.policy == "random":
+            a = acts[i]
+        else:
+            a1 = chase_actions(out[0] if i else obs, 0.1, gen).view(n, 1)
+            a = torch.cat([a1, torch.randint(0, 8, (n, na - 1), generator=gen, device=dev, dtype=torch.int32)], 1) \
+                if na > 1 else a1
+        return env.step(a, out=out)
+
+    for i in range(W):
+        one_step(i)
+    _, _, _, cnt0 = env.episode_stats()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    pending = []
+    rrd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        ev[i][0].record()
+        if args.policy == "random":
+            env.step(acts[W + i], out=out)  # exactly one kernel launch between the two events
+        else:
+            one_step(W + i)
+        ev[i][1].record()
+        if world > 1 and (i + 1) % args.log_interval == 0:
+            lr = env.episode_stats()[0]
+            pending.append(rrd.all_gather_returns(lr, async_op=True))
+    for _, work in pending:
+        if work is not None:
+            work.wait()
+    torch.cuda.synchronize()
+    rrd.barrier()
+    dt = time.perf_counter() - t0
+    dt = rrd.reduce_max(dt, dev)
+    # steps that only re-placed a finished arena are not counted as env steps
+    _, _, _, cnt1 = env.episode_stats()
+    resets = int((cnt1 - cnt0).sum().item()) - int(out[2].sum().item())
+    local_steps = n * K - max(resets, 0)
+    total_steps = rrd.reduce_sum(float(local_steps), dev)
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / K
+    kern_ms = rrd.reduce_max(kern_ms, dev)
+    status_bits = int(torch.bitwise_and(out[5], ~1024 & ~256).max().item())
+
+    if rank == 0:
+        bytes_per_step = p.algorithmic_bytes_per_step(na)            # G 601 B, T 149 B
+        achieved = bytes_per_step * n / (kern_ms * 1e-3) / 1e9         # GB/s, one launch = n arena-steps
+        traffic = None
+        tfile = os.path.join(REPO, "profiles", "traffic.json")          # PMC-derived HBM bytes per launch, if measured
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(f"{args.preset}_{args.dtype}_{n}")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "env_steps_per_sec", "value": total_steps / dt, "unit": "env-steps/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{n} parallel arenas per GPU, SimpleDuel3 preset {args.preset} "
+                                   f"({p.nr_happy}+{p.nr_grumpy} robots, {p.nb_pos}+{p.nb_neg} balls, "
+                                   f"{int(p.arena_w)}x{int(p.arena_h)}), {args.policy}-policy rollout, {na} action(s)/arena, "
+                                   f"auto-reset on done, one wavefront per arena",
+                       "arenas_per_gpu": n, "preset": args.preset, "policy": args.policy,
+                       "sharding": f"dp{world} (independent arena shards, returns all-gathered every "
+                                   f"{args.log_interval} steps)" if world > 1 else "single GPU",
+                       "fault_status_bits_seen": status_bits},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_step", "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": bytes_per_step,
+                         "record_bytes_per_env": env.state_bytes_per_env(),
+                         "note": "latency/VALU-bound by construction: 12 dependent sub-steps of fp64 geometry per "
+                                 "149-601 B of state; the HBM fraction is reported because BASELINE.json asks for it"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.preset, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    rrd.barrier()
+    env.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -4,6 +4,11 @@ There is NO CPU fallback: if the HIP library is missing or cannot be loaded this
 import ctypes as C
 import os
 
+# PyTorch-ROCm bundles its own libamdhip64; it must be the HIP runtime this process loads FIRST so that the
+# library below (linked against the same soname) shares it -- device pointers and streams handed across the
+# C-ABI are only meaningful inside one runtime instance.
+import torch  # noqa: F401  (import order matters)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libroborugby_amd.so")
 
