@@ -10,7 +10,8 @@ import os
 import torch  # noqa: F401  (import order matters)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libroborugby_amd.so")
+# RR_LIB_PATH lets tools/ A/B-test alternative builds of the same ABI (kernel tuning); default = the in-tree build
+LIB_PATH = os.environ.get("RR_LIB_PATH", os.path.join(HERE, "libroborugby_amd.so"))
 
 
 class RRConfig(C.Structure):

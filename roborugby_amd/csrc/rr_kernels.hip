@@ -42,9 +42,12 @@ template <class C> __device__ __forceinline__ void store_record(const Arena<C> &
 }
 
 constexpr int WAVES_PER_BLOCK = 4;
+#ifndef RR_MIN_WAVES_PER_SIMD
+#define RR_MIN_WAVES_PER_SIMD 4 // <=128 VGPRs: 4 waves/SIMD measured 4x faster than the 1 wave/SIMD the allocator picks unconstrained
+#endif
 
 template <class C, typename O>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_step(SimParams<typename C::Real> sp, typename C::Real *recs,
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, RR_MIN_WAVES_PER_SIMD) void k_step(SimParams<typename C::Real> sp, typename C::Real *recs,
                                                               int32_t *irecs, int n, const int32_t *actions,
                                                               const float *thrust, int na, O *obs, O *reward,
                                                               uint8_t *done, O *obs_g, O *reward_g, int32_t *status) {

@@ -30,7 +30,13 @@
 
 #if defined(__HIPCC__)
 #define RR_HD __host__ __device__ __forceinline__
+// rarely-taken paths (contact responses, reset).  Measured on MI355X: inlining them too and capping registers
+// with __launch_bounds__ (4 waves/SIMD) beats real calls, whose ABI pins values in high callee-saved VGPRs.
+#ifdef RR_OUTLINE_RARE
 #define RR_HDN __host__ __device__ __noinline__
+#else
+#define RR_HDN __host__ __device__ __forceinline__
+#endif
 #else
 #define RR_HD inline
 #define RR_HDN
@@ -79,6 +85,36 @@ RR_HD float m_fmod(float a, float b) { return ::fmodf(a, b); }
 RR_HD float m_abs(float x) { return ::fabsf(x); }
 RR_HD float m_rint(float x) { return ::rintf(x); }
 
+// sin & cos of one angle.  fp64: Cody-Waite reduction by pi/2 + the fdlibm kernel polynomials (|x| stays below
+// a few pi here: angles are degrees in [-90, 810) converted to radians).  Absolute error < 1e-16, which is what
+// matters for corner offsets of length ~22; much cheaper in registers and instructions than the generic ocml
+// path with its Payne-Hanek fallback, and identical on the host emulation and on the GPU.
+RR_HD void m_sincos(double x, double &s, double &c) {
+    const double fn = ::rint(x * 6.36619772367581382433e-01);
+    const int n = (int)fn;
+    const double z0 = x - fn * 1.57079632673412561417e+00; // pio2_1: first 33 bits of pi/2 (exact product)
+    const double w0 = fn * 6.07710050650619224932e-11;      // pio2_1t
+    const double y = z0 - w0, yl = (z0 - y) - w0;
+    const double z = y * y;
+    // __kernel_sin(y, yl, 1)
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double v = z * y;
+    const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    const double ks = y - ((z * (0.5 * yl - v * rs) - yl) - v * S1);
+    // __kernel_cos(y, yl)
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double w = z * z;
+    const double rc = z * (C1 + z * (C2 + z * C3)) + (w * w) * (C4 + z * (C5 + z * C6));
+    const double hz = 0.5 * z, wc = 1.0 - hz;
+    const double kc = wc + (((1.0 - wc) - hz) + (z * rc - y * yl));
+    const int q = n & 3;
+    s = (q == 0) ? ks : (q == 1) ? kc : (q == 2) ? -ks : -kc;
+    c = (q == 0) ? kc : (q == 1) ? -ks : (q == 2) ? -kc : ks;
+}
+RR_HD void m_sincos(float x, float &s, float &c) { s = ::sinf(x); c = ::cosf(x); }
+
 template <typename R> RR_HD R inf_() { return (R)INFINITY; }
 template <typename R> RR_HD bool is_inf(R x) { return x == inf_<R>() || x == -inf_<R>(); }
 template <typename R> RR_HD bool is_nan(R x) { return x != x; }
@@ -120,21 +156,18 @@ template <typename R> RR_HD void slope_yint(V2<R> a, V2<R> b, R &m, R &c, int &s
     else if (m == -inf_<R>()) c = inf_<R>();
     else c = a.y - a.x * m;
 }
-// MyUtils.py:61-85 with the two slope/intercept pairs already known
+// MyUtils.py:61-85 with the two slope/intercept pairs already known.  Written with selects instead of
+// branches (the values are the reference's in every case; lanes in a wave take different cases).
 template <typename R> RR_HD V2<R> intersect_mb(R m1, R b1, R x1, R m2, R b2, R x2) {
+    const bool i1 = is_inf(m1), i2 = is_inf(m2);
+    const bool par = (m1 == m2) | (i1 & i2);
+    R gx = (b1 - b2) / (m2 - m1);
+    R x = i1 ? x1 : (i2 ? x2 : gx);
+    const bool use1 = i2 | (!i1 & (m_abs(b1) < m_abs(b2))); // which line formula gives y
+    R y = use1 ? (m1 * x + b1) : (m2 * x + b2);
     V2<R> r;
-    if (m1 == m2 || (is_inf(m1) && is_inf(m2))) { r.x = inf_<R>(); r.y = inf_<R>(); return r; }
-    if (is_inf(m1)) {
-        r.x = x1;
-        r.y = m2 * r.x + b2;
-    } else if (is_inf(m2)) {
-        r.x = x2;
-        r.y = m1 * r.x + b1;
-    } else {
-        r.x = (b1 - b2) / (m2 - m1);
-        if (m_abs(b1) < m_abs(b2)) r.y = m1 * r.x + b1;
-        else r.y = m2 * r.x + b2;
-    }
+    r.x = par ? inf_<R>() : x;
+    r.y = par ? inf_<R>() : y;
     return r;
 }
 template <typename R> RR_HD V2<R> line_intersection(Seg<R> l1, Seg<R> l2, int &st) {
@@ -143,10 +176,11 @@ template <typename R> RR_HD V2<R> line_intersection(Seg<R> l1, Seg<R> l2, int &s
     slope_yint(l2.a, l2.b, m2, b2, st);
     return intersect_mb<R>(m1, b1, l1.a.x, m2, b2, l2.a.x);
 }
-// MyUtils.py:88-94
+// MyUtils.py:88-94 (non-short-circuit form: same truth table, no branches)
 template <typename R> RR_HD bool within(V2<R> p, Seg<R> l, R buf) {
-    return ((l.a.x - buf <= p.x && p.x <= l.b.x + buf) || (l.b.x - buf <= p.x && p.x <= l.a.x + buf)) &&
-           ((l.a.y - buf <= p.y && p.y <= l.b.y + buf) || (l.b.y - buf <= p.y && p.y <= l.a.y + buf));
+    const bool wx = ((l.a.x - buf <= p.x) & (p.x <= l.b.x + buf)) | ((l.b.x - buf <= p.x) & (p.x <= l.a.x + buf));
+    const bool wy = ((l.a.y - buf <= p.y) & (p.y <= l.b.y + buf)) | ((l.b.y - buf <= p.y) & (p.y <= l.a.y + buf));
+    return wx & wy;
 }
 // MyUtils.py:97-110
 template <typename R> RR_HD R angle_degrees(V2<R> a, V2<R> b, int &st) {
@@ -200,12 +234,14 @@ template <class C> struct Arena {
     R rel[NR][8];   // corner offsets TL,TR,BL,BR (x,y) for the current rotation
     R irel[NR][8];  // corner offsets of the ball's inner square at rot+45 (diameter end points)
     R irot[NR];     // rotation irel was built for (NaN = stale)
+    R sm[NR][4], sc[NR][4]; // slope / y-intercept of the four sides (get_slope_yint, MyUtils.py:44-58) for the current pose
     R ax[NR], ay[NR], arot[NR], arel[NR][8]; // pose at frame begin (= ring entry written this frame)
     R prel[NR][8];  // corner offsets for the persisted previous-move pose (px,py,prot)
     R psx[NR], psy[NR]; // robot centre at step begin (rectDblPriorStep)
     R bfx[NB], bfy[NB], pfx[NB], pfy[NB];
     int32_t bmass[NB];
     R lf[3 * 4 * NR], lb[3 * 4 * NR]; // lidar candidates
+    R lid[6];                          // capped minima: front/back per ray
     static constexpr int P_REALS = (int)(sizeof(P) / sizeof(R));
     static constexpr int I_INTS = (int)(sizeof(I) / sizeof(int32_t));
     static constexpr int P_STRIDE = (P_REALS + 15) / 16 * 16; // record strides in HBM (128-B multiples)
@@ -231,18 +267,21 @@ template <typename R> RR_HD void fr_set_cy(FR<R> &f, R v) { fr_move<R>(f, (R)0, 
 // body of the rotation setter (MyUtils.py:284-316): rotate the initial corners (+-hw, +-hh) by
 // 360-rot degrees and renormalise them to the corner distance
 template <typename R> RR_HD void corners_for(R rot, R hw, R hh, R cdist, R *rel) {
-    const R ix[4] = { -hw, hw, -hw, hw }, iy[4] = { -hh, -hh, hh, hh };
+    // initial corners TL(-hw,-hh) TR(hw,-hh) BL(-hw,hh) BR(hw,hh): BR = -TL and BL = -TR, and every operation
+    // below is odd-symmetric in (x,y), so two corners are computed and two are exact negations
     if (rot == (R)0) {
-        for (int k = 0; k < 4; k++) { rel[2 * k] = ix[k]; rel[2 * k + 1] = iy[k]; }
+        rel[0] = -hw; rel[1] = -hh; rel[2] = hw; rel[3] = -hh; rel[4] = -hw; rel[5] = hh; rel[6] = hw; rel[7] = hh;
         return;
     }
-    R rad = radians<R>((R)360 - rot);
-    R c = m_cos(rad), s = m_sin(rad);
-    for (int k = 0; k < 4; k++) {
-        R qx = ix[k] * c - iy[k] * s, qy = ix[k] * s + iy[k] * c;
+    R c, s;
+    m_sincos(radians<R>((R)360 - rot), s, c);
+    const R ix[2] = { -hw, hw }, iy = -hh; // TL, TR
+    for (int k = 0; k < 2; k++) {
+        R qx = ix[k] * c - iy * s, qy = ix[k] * s + iy * c;
         R d = m_sqrt(qx * qx + qy * qy);
-        rel[2 * k] = qx * cdist / d;
-        rel[2 * k + 1] = qy * cdist / d;
+        R ax = qx * cdist / d, ay = qy * cdist / d;
+        rel[2 * k] = ax; rel[2 * k + 1] = ay;                  // TL / TR
+        rel[2 * (3 - k)] = -ax; rel[2 * (3 - k) + 1] = -ay;    // BR / BL
     }
 }
 template <typename R> RR_HD void fr_edges_from_rel(FR<R> &f) { // MyUtils.py:318-322
@@ -303,10 +342,11 @@ template <typename R> RR_HD void rob_clamp(FR<R> &f, const SimParams<R> &sp) {
     if (f.b >= sp.H) fr_set_bottom<R>(f, sp.H - buffer);
 }
 template <typename R> RR_HD void rob_move_linear(FR<R> &f, const SimParams<R> &sp, R vel) {
-    R rad = radians<R>(f.rot);
+    R sn, cs;
+    m_sincos(radians<R>(f.rot), sn, cs);
     R px = f.cx, py = f.cy;
-    fr_set_left<R>(f, f.l + m_cos(rad) * vel);
-    fr_set_top<R>(f, f.t + m_sin(rad) * vel * (R)-1);
+    fr_set_left<R>(f, f.l + cs * vel);
+    fr_set_top<R>(f, f.t + sn * vel * (R)-1);
     if (rob_hit_wall<R>(f, sp)) { fr_set_cx<R>(f, px); fr_set_cy<R>(f, py); }
     rob_clamp<R>(f, sp);
 }
@@ -314,9 +354,10 @@ template <typename R> RR_HD void rob_move_angular(FR<R> &f, const SimParams<R> &
     R rot_prior = f.rot, px = f.cx, py = f.cy;
     fr_set_rot<R>(f, f.rot + w, sp.rob_cdist);
     if (has_c) {
-        R rad = radians<R>(f.rot + adj);
-        fr_set_cx<R>(f, c.x + (R)16 * m_cos(rad));
-        fr_set_cy<R>(f, c.y - (R)16 * m_sin(rad));
+        R sn, cs;
+        m_sincos(radians<R>(f.rot + adj), sn, cs);
+        fr_set_cx<R>(f, c.x + (R)16 * cs);
+        fr_set_cy<R>(f, c.y - (R)16 * sn);
     }
     if (rob_hit_wall<R>(f, sp)) {
         fr_set_cx<R>(f, px); fr_set_cy<R>(f, py);
@@ -338,8 +379,9 @@ template <class C> RR_HD void robot_move_lane(Arena<C> &A, const SimParams<typen
     } else {
         R w = (Rt > 0 || L < 0) ? (R).6 : (R)-.6;
         R off = (Rt != 0) ? (R)90 : (R)-90; // pivot = left track (rot+90) when the right one drives
-        R rad = radians<R>(f.rot + off);
-        V2<R> c = { f.cx + (R)16 * m_cos(rad), f.cy - (R)16 * m_sin(rad) };
+        R sn, cs;
+        m_sincos(radians<R>(f.rot + off), sn, cs);
+        V2<R> c = { f.cx + (R)16 * cs, f.cy - (R)16 * sn };
         rob_move_angular<R>(f, sp, w, true, c, -off);
     }
     store_robot(A, r, f);
@@ -368,6 +410,28 @@ template <class C> RR_HD void refresh_inner_lane(Arena<C> &A, const SimParams<ty
     corners_for<R>(py_mod<R>(rot + (R)45 + (R)720, (R)360), sp.inner_h, sp.inner_h, sp.inner_cdist, A.irel[r]);
 }
 
+// side slope/intercept cache: one lane per (robot, side); must follow every robot pose change
+template <class C> RR_HD void refresh_sides(Arena<C> &A) {
+    using R = typename C::Real;
+    RR_FOR_LANES(l) {
+        if (l < 4 * C::NR) {
+            int r = l >> 2, sd = l & 3, st = 0;
+            Seg<R> g = robot_side(A, r, sd);
+            R m, c;
+            slope_yint<R>(g.a, g.b, m, c, st);
+            A.sm[r][sd] = m; A.sc[r][sd] = c;
+        }
+    }
+    RR_SYNC();
+}
+// Exact broad phase.  A hit of robots_collided / ball_robot_collided needs an intersection point inside the
+// bounding boxes of BOTH segments (MyUtils.py:88-94): every side point is within |corner| = 22.36 of its robot
+// centre, every diameter point within 7*sqrt(2) = 9.9 of the ball centre, a corner hit needs |corner-ball| < 7.
+// So centres farther apart than 2*22.36 (robots) or 22.36+9.9 (ball-robot) can never hit; the constants below
+// leave > 0.7 px of slack, far above any rounding.  Arenas where nothing is close skip the narrow phase.
+template <typename R> RR_HD R cull_rr2() { return (R)(45.5 * 45.5); }
+template <typename R> RR_HD R cull_br2() { return (R)(33.0 * 33.0); }
+
 // ------------------------------------------------------------------------------------------------ contact predicates, one task per lane
 // robots_collided (RR_TrashyPhysics.py:18-24): task = (pair, side of bot1, side of bot2)
 template <class C> RR_HD void pair_of(int p, int n, int &i, int &j) { // p-th (i<j) pair in nested-loop order
@@ -385,11 +449,15 @@ template <class C> RR_HD uint32_t detect_robot_pairs(const Arena<C> &A) {
             bool hit = false;
             int t = base + l;
             if (t < NT) {
-                int i, j, st = 0;
+                int i, j;
                 pair_of<C>(t >> 4, C::NR, i, j);
-                Seg<R> s1 = robot_side(A, i, (t >> 2) & 3), s2 = robot_side(A, j, t & 3);
-                V2<R> p = line_intersection<R>(s1, s2, st);
-                hit = within<R>(p, s1, (R)0) && within<R>(p, s2, (R)0);
+                R dx = A.p.rcx[j] - A.p.rcx[i], dy = A.p.rcy[j] - A.p.rcy[i];
+                if (dx * dx + dy * dy <= cull_rr2<R>()) {
+                    int s1 = (t >> 2) & 3, s2 = t & 3;
+                    Seg<R> g1 = robot_side(A, i, s1), g2 = robot_side(A, j, s2);
+                    V2<R> p = intersect_mb<R>(A.sm[i][s1], A.sc[i][s1], g1.a.x, A.sm[j][s2], A.sc[j][s2], g2.a.x);
+                    hit = within<R>(p, g1, (R)0) & within<R>(p, g2, (R)0);
+                }
             }
             RR_VOTE(m, l, hit);
         }
@@ -400,28 +468,42 @@ template <class C> RR_HD uint32_t detect_robot_pairs(const Arena<C> &A) {
 }
 // ball_robot_collided (RR_TrashyPhysics.py:39-69): task = (ball, robot, diameter); each lane tests two
 // corners against the radius and its diameter against the four sides.  Bit (b*NR + r) of the result.
-template <class C> RR_HD uint32_t detect_ball_robot(const Arena<C> &A) {
+template <class C> RR_HD uint32_t detect_ball_robot(Arena<C> &A, const SimParams<typename C::Real> &sp) {
     using R = typename C::Real;
     constexpr int NT = C::NB * C::NR * 2;
+    uint64_t close = 0;
+    RR_FOR_LANES(l) {
+        bool c = false;
+        if (l < NT) {
+            int pr = l >> 1, r = pr % C::NR, b = pr / C::NR;
+            R dx = A.p.bcx[b] - A.p.rcx[r], dy = A.p.bcy[b] - A.p.rcy[r];
+            c = dx * dx + dy * dy <= cull_br2<R>();
+        }
+        RR_VOTE(close, l, c);
+    }
+    if (!close) return 0;
+    // narrow phase: the inner-square corner offsets (rot+45) are only needed now
+    RR_FOR_LANES(l) {
+        if (l < C::NR) refresh_inner_lane(A, sp, l);
+    }
+    RR_SYNC();
     uint64_t m = 0;
     RR_FOR_LANES(l) {
         bool hit = false;
-        if (l < NT) {
+        if ((close >> l) & 1) {
             int d = l & 1, pr = l >> 1, r = pr % C::NR, b = pr / C::NR, st = 0;
             V2<R> bc = { A.p.bcx[b], A.p.bcy[b] };
-            hit = dist<R>(robot_corner(A, r, 2 * d), bc) < (R)7 || dist<R>(robot_corner(A, r, 2 * d + 1), bc) < (R)7;
+            hit = (dist<R>(robot_corner(A, r, 2 * d), bc) < (R)7) | (dist<R>(robot_corner(A, r, 2 * d + 1), bc) < (R)7);
             // diameters (TL->BR) and (TR->BL) of the inner square
             int ca = d == 0 ? TL : TR, cb = d == 0 ? BR : BL;
             Seg<R> dia = { { bc.x + A.irel[r][2 * ca], bc.y + A.irel[r][2 * ca + 1] },
                            { bc.x + A.irel[r][2 * cb], bc.y + A.irel[r][2 * cb + 1] } };
             R md, cd;
             slope_yint<R>(dia.a, dia.b, md, cd, st);
-            for (int s = 0; s < 4; s++) {
-                Seg<R> side = robot_side(A, r, s);
-                R ms, cs;
-                slope_yint<R>(side.a, side.b, ms, cs, st);
-                V2<R> p = intersect_mb<R>(ms, cs, side.a.x, md, cd, dia.a.x);
-                hit = hit || (within<R>(p, side, (R)0) && within<R>(p, dia, (R)0));
+            for (int sd = 0; sd < 4; sd++) {
+                Seg<R> side = robot_side(A, r, sd);
+                V2<R> p = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, md, cd, dia.a.x);
+                hit = hit | (within<R>(p, side, (R)0) & within<R>(p, dia, (R)0));
             }
         }
         RR_VOTE(m, l, hit);
@@ -487,8 +569,10 @@ template <class C> RR_HDN void apply_force_to_ball(Arena<C> &A, int r, int b, ui
     force_diameters(A, r, bc, dia);
     R fx = A.bfx[b], fy = A.bfy[b];
     bool done = false;
+    #pragma unroll 1
     for (int s = 0; s < 4 && !done; s++) {
         Seg<R> side = robot_side(A, r, s);
+#pragma unroll 1
         for (int d = 0; d < 2 && !done; d++) {
             V2<R> I = line_intersection<R>(side, dia[d], st);
             if (within<R>(I, side, (R)0) && within<R>(I, dia[d], cbuf)) {
@@ -503,6 +587,7 @@ template <class C> RR_HDN void apply_force_to_ball(Arena<C> &A, int r, int b, ui
     if (!done) {
         R px, py; const R *prel;
         robot_prev_frame(A, r, bots_moved, px, py, prel);
+        #pragma unroll 1
         for (int c = 0; c < 4 && !done; c++) {
             V2<R> bcn = robot_corner(A, r, c);
             R dc = dist<R>(bcn, bc);
@@ -543,10 +628,12 @@ template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, int r, int b, ui
     robot_prev_frame(A, r, bots_moved, px, py, prel);
     R mvx = 0, mvy = 0;
     bool done = false;
+    #pragma unroll 1
     for (int s = 0; s < 4 && !done; s++) {
         Seg<R> side = robot_side(A, r, s);
         int ca = side_a(s), cb = side_b(s);
         Seg<R> sprev = { { px + prel[2 * ca], py + prel[2 * ca + 1] }, { px + prel[2 * cb], py + prel[2 * cb + 1] } };
+#pragma unroll 1
         for (int d = 0; d < 2 && !done; d++) {
             V2<R> I = line_intersection<R>(side, dia[d], st);
             if (within<R>(I, side, (R)0) && within<R>(I, dia[d], (R)0)) {
@@ -563,6 +650,7 @@ template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, int r, int b, ui
             }
         }
     }
+    #pragma unroll 1
     for (int c = 0; c < 4 && !done; c++) {
         V2<R> bcn = robot_corner(A, r, c);
         R dc = dist<R>(bcn, bc);
@@ -675,13 +763,14 @@ template <class C> RR_HD void ball_undo_lane(Arena<C> &A, int b) {
 }
 
 // ------------------------------------------------------------------------------------------------ sub-step pieces (RR_EnvBase.py:303-454)
-template <class C> RR_HD void resolve_bot_collisions(Arena<C> &A, uint32_t &bots_moved, uint32_t &naughty, int &st) {
+template <class C> RR_HDN void resolve_bot_collisions(Arena<C> &A, uint32_t &bots_moved, uint32_t &naughty, int &st) {
     if (C::NPR == 0) return;
     uint32_t pairs = detect_robot_pairs(A);
     int attempts = 0;
     while (pairs) {
         attempts++;
         if (attempts > C::NR) { st |= ST_BOT_RESOLVE_FAIL; return; }
+#pragma unroll 1
         for (int p = 0; p < C::NPR; p++) {
             if (!(pairs & (1u << p))) continue;
             int i, j;
@@ -697,6 +786,7 @@ template <class C> RR_HD void resolve_bot_collisions(Arena<C> &A, uint32_t &bots
             }
             RR_SYNC();
         }
+        refresh_sides(A);
         pairs = detect_robot_pairs(A);
     }
 }
@@ -706,7 +796,7 @@ template <class C> RR_HD void refresh_inner(Arena<C> &A, const SimParams<typenam
     }
     RR_SYNC();
 }
-template <class C> RR_HD bool resolve_ball_collisions(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t bots_moved, int &st) {
+template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t bots_moved, int &st) {
     bool naughty = true;
     int count = 0;
     while (naughty) {
@@ -714,6 +804,7 @@ template <class C> RR_HD bool resolve_ball_collisions(Arena<C> &A, const SimPara
         if (count > 10) return false;
         naughty = false;
         uint64_t bb = detect_ball_pairs(A);
+#pragma unroll 1
         for (int p = 0; p < C::NPB; p++) {
             if (!(bb & (1ull << p))) continue;
             int i, j;
@@ -721,7 +812,8 @@ template <class C> RR_HD bool resolve_ball_collisions(Arena<C> &A, const SimPara
             naughty = true;
             bounce_balls(A, i, j, st);
         }
-        uint32_t br = detect_ball_robot(A);
+        uint32_t br = detect_ball_robot(A, sp);
+#pragma unroll 1
         for (int p = 0; p < C::NB * C::NR; p++) {
             if (!(br & (1u << p))) continue;
             naughty = true;
@@ -739,7 +831,7 @@ template <class C> RR_HD bool resolve_ball_collisions(Arena<C> &A, const SimPara
     return true;
 }
 template <class C>
-RR_HD void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &balls_moved,
+RR_HDN void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &balls_moved,
                                  uint32_t &bots_moved, int &st) {
     bool naughty = true;
     int count = 0;
@@ -752,14 +844,15 @@ RR_HD void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real> 
         }
         uint32_t nbots = 0, nballs = 0;
         uint64_t bb = detect_ball_pairs(A);
+#pragma unroll 1
         for (int p = 0; p < C::NPB; p++) {
             if (!(bb & (1ull << p))) continue;
             int i, j;
             pair_of<C>(p, C::NB, i, j);
             nballs |= (1u << i) | (1u << j);
         }
-        refresh_inner(A, sp);
-        uint32_t br = detect_ball_robot(A);
+        uint32_t br = detect_ball_robot(A, sp);
+#pragma unroll 1
         for (int p = 0; p < C::NB * C::NR; p++) {
             if (!(br & (1u << p))) continue;
             nballs |= 1u << (p / C::NR);
@@ -776,6 +869,7 @@ RR_HD void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real> 
                 if (l < C::NB && (uballs & (1u << l))) ball_undo_lane(A, l);
             }
             RR_SYNC();
+            if (ubots) refresh_sides(A);
         }
         if (count > limit && naughty && !(ubots | uballs)) { st |= ST_UNDO_FAIL; return; }
     }
@@ -800,10 +894,11 @@ template <class C> RR_HD void substep(Arena<C> &A, const SimParams<typename C::R
         if (l < C::NR) robot_move_lane(A, sp, l);
     }
     RR_SYNC();
+    refresh_sides(A);
     resolve_bot_collisions(A, bots_moved, naughty, st);
-    refresh_inner(A, sp);
     { // _push_balls (RR_EnvBase.py:335-339): frozen hit list, ball-major order
-        uint32_t br = detect_ball_robot(A);
+        uint32_t br = detect_ball_robot(A, sp);
+#pragma unroll 1
         for (int p = 0; p < C::NB * C::NR; p++) {
             if (!(br & (1u << p))) continue;
             apply_force_to_ball(A, p % C::NR, p / C::NR, bots_moved, st);
@@ -827,7 +922,7 @@ template <class C> RR_HD void substep(Arena<C> &A, const SimParams<typename C::R
 // ------------------------------------------------------------------------------------------------ observation (RR_Observers.py:301-406)
 // lidar: one lane per (ray, rect, side); candidates go to LDS, the wave-uniform tail takes the minima
 template <class C, typename O>
-RR_HD bool observe(Arena<C> &A, const SimParams<typename C::Real> &sp, int team, int ridx, int bidx, O *out, int &st) {
+RR_HDN bool observe(Arena<C> &A, const SimParams<typename C::Real> &sp, int team, int ridx, int bidx, O *out, int &st) {
     using R = typename C::Real;
     if (ridx < 0) {
         if (team == 1 && C::NRH == 0) return false;
@@ -862,17 +957,22 @@ RR_HD bool observe(Arena<C> &A, const SimParams<typename C::Real> &sp, int team,
         }
     }
     RR_SYNC();
-    R lid[6]; // front, back per ray
-    for (int k = 0; k < 3; k++) {
-        R f = inf_<R>(), b = inf_<R>();
-        for (int q = 0; q < 4 * C::NR; q++) {
-            R vf = A.lf[k * 4 * C::NR + q], vb = A.lb[k * 4 * C::NR + q];
-            if (vf < f) f = vf;
-            if (vb < b) b = vb;
+    RR_FOR_LANES(l) { // min over (rect, side) in list order: one lane per (ray, direction)
+        if (l < 6) {
+            const R *src = (l & 1) ? A.lb : A.lf;
+            const int k = l >> 1;
+            R best = inf_<R>();
+#pragma unroll 1
+            for (int q = 0; q < 4 * C::NR; q++) {
+                R v = src[k * 4 * C::NR + q];
+                if (v < best) best = v;
+            }
+            A.lid[l] = py_min<R>(best, (R)150);
         }
-        lid[2 * k] = py_min<R>(f, (R)150);
-        lid[2 * k + 1] = py_min<R>(b, (R)150);
     }
+    RR_SYNC();
+    R lid[6]; // front, back per ray
+    for (int k = 0; k < 6; k++) lid[k] = A.lid[k];
     V2<R> rc = { A.p.rcx[ridx], A.p.rcy[ridx] }, bc = { A.p.bcx[bidx], A.p.bcy[bidx] };
     V2<R> good = { sp.W, sp.H }, bad = { (R)0, (R)0 };
     R ball_angle = angle_degrees<R>(rc, bc, st);
@@ -906,11 +1006,11 @@ template <class C> RR_HD void derive(Arena<C> &A, const SimParams<typename C::Re
             corners_for<R>(A.p.rrot[l], (R)10, (R)20, sp.rob_cdist, A.rel[l]);
             if (!is_nan(A.p.px[l]))
                 corners_for<R>(py_mod<R>(A.p.prot[l] + (R)720, (R)360), (R)10, (R)20, sp.rob_cdist, A.prel[l]);
-            A.irot[l] = (R)NAN;
-            refresh_inner_lane(A, sp, l);
+            A.irot[l] = (R)NAN; // inner-square offsets are built lazily by the first narrow phase that needs them
         }
     }
     RR_SYNC();
+    refresh_sides(A);
 }
 // "clean" robot pose: centre exactly (x,y), edges re-derived like the rotation setter, no history
 template <class C> RR_HD void robot_set_clean_lane(Arena<C> &A, const SimParams<typename C::Real> &sp, int r,
@@ -1069,6 +1169,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     R dist_sum0 = (R)0;
     {
         V2<R> o0 = { (R)0, (R)0 };
+#pragma unroll 1
         for (int b = 0; b < C::NBP; b++) { V2<R> c = { A.p.bcx[b], A.p.bcy[b] }; dist_sum0 = dist_sum0 + dist<R>(o0, c); }
     }
     RR_FOR_LANES(l) {
@@ -1091,12 +1192,15 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     if (!thrust) for (int q = 0; q < na && q < C::NR; q++) { int a = actions[q]; if (a < 0 || a > 7) st |= ST_BAD_ACTION; }
     RR_SYNC();
     uint32_t naughty = 0;
+#pragma unroll 1
     for (int f = 0; f < 12; f++) substep(A, sp, naughty, st); // MOVES_PER_FRAME
     // ---- on_step_end: NaughtyBots, ChasePosBall, PushPosBallsToGoal (SURVEY 3.1 accumulation order)
     R rew_h = (R)0, rew_g = (R)0;
     for (int r = 0; r < C::NR; r++) if (naughty & (1u << r)) { if (r < C::NRH) rew_h -= (R).005; else rew_g -= (R).005; }
+#pragma unroll 1
     for (int r = 0; r < C::NR; r++) {
         V2<R> rc = { A.p.rcx[r], A.p.rcy[r] }, pc = { A.psx[r], A.psy[r] };
+#pragma unroll 1
         for (int b = 0; b < C::NBP; b++) {
             V2<R> bc = { A.p.bcx[b], A.p.bcy[b] };
             R now = dist<R>(rc, bc), prior = dist<R>(pc, bc);
@@ -1106,6 +1210,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     {
         R s1 = (R)0;
         V2<R> o0 = { (R)0, (R)0 };
+#pragma unroll 1
         for (int b = 0; b < C::NBP; b++) { V2<R> c = { A.p.bcx[b], A.p.bcy[b] }; s1 = s1 + dist<R>(o0, c); }
         R delta = s1 - dist_sum0;
         rew_h += delta * sp.mult_ball;
