@@ -177,8 +177,8 @@ def main():
             "config": {"workload": f"{n} parallel arenas per GPU, SimpleDuel3 preset {args.preset} "
                                    f"({p.nr_happy}+{p.nr_grumpy} robots, {p.nb_pos}+{p.nb_neg} balls, "
                                    f"{int(p.arena_w)}x{int(p.arena_h)}), {args.policy}-policy rollout, {na} action(s)/arena, "
-                                   f"auto-reset on done, one wavefront per arena",
-                       "arenas_per_gpu": n, "preset": args.preset, "policy": args.policy,
+                                   f"auto-reset on done, {env.lanes_per_env()} lanes per arena ({64 // env.lanes_per_env()} arena(s) per wavefront)",
+                       "arenas_per_gpu": n, "preset": args.preset, "policy": args.policy, "lanes_per_arena": env.lanes_per_env(),
                        "sharding": f"dp{world} (independent arena shards, returns all-gathered every "
                                    f"{args.log_interval} steps)" if world > 1 else "single GPU",
                        "fault_status_bits_seen": status_bits},

@@ -115,8 +115,10 @@ int rr_set_poses(rr_env *env, const double *robots_xyr, const double *balls_xyv,
 int rr_episode_stats(rr_env *env, float *last_return, float *last_return_g, int32_t *last_len,
                      int32_t *episodes_done, void *stream);
 
-/* Introspection used by bench.py for the roofline line. */
+/* Introspection used by bench.py for the roofline line: bytes of the per-arena HBM record, and how many lanes of
+ * a wavefront work on one arena (64 = one wavefront per arena; smaller = several arenas packed per wavefront). */
 int rr_state_bytes_per_env(const rr_env *env, int64_t *bytes);
+int rr_lanes_per_env(const rr_env *env, int32_t *lanes);
 
 #ifdef __cplusplus
 }

@@ -43,6 +43,7 @@ SYMBOLS = {
     "rr_set_poses": (C.c_int, [_vp, _vp, _vp, _vp]),
     "rr_episode_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "rr_state_bytes_per_env": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "rr_lanes_per_env": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
 }
 
 _lib = None

@@ -1,9 +1,10 @@
 // rr_kernels.hip -- gfx950 kernels + the C-ABI (include/roborugby_amd.h) of the batched RoboRugby simulator.
 //
-// Launch geometry: 256-thread workgroups = 4 wavefronts = 4 arenas; every wave owns a private LDS
-// slice (Arena<C>) and never talks to another wave, so there is no workgroup barrier anywhere and
-// no inter-workgroup traffic -- any blockIdx -> XCD placement is equally good (arenas share nothing,
-// there is no L2 reuse to protect).  A 65,536-arena launch is 16,384 workgroups >> 256 CUs.
+// Launch geometry: 256-thread workgroups = 4 wavefronts; a wavefront is cut into 64/VW virtual waves of VW
+// lanes and every virtual wave owns one arena (VW = 64: one wavefront per arena; VW = 16: four arenas per
+// wavefront, ...).  Each arena has a private LDS slice (Arena<C>) and never talks to another arena, so there
+// is no workgroup barrier anywhere and no inter-workgroup traffic -- any blockIdx -> XCD placement is equally
+// good (arenas share nothing, there is no L2 reuse to protect).  65,536 arenas = 1,024..16,384 workgroups.
 //
 // HBM layout: one record of P_STRIDE reals + one of I_STRIDE int32 per arena, both padded to 128-B
 // multiples.  Inside a record the fields are entity-minor (SoA over robots / balls), and a wave
@@ -15,6 +16,8 @@
 #include <cmath>
 #include <new>
 #include <string>
+#include <type_traits>
+#include <cstdlib>
 
 #include "../../include/roborugby_amd.h"
 #include "rr_sim.hpp"
@@ -26,22 +29,23 @@ template <class C> __device__ __forceinline__ void load_record(Arena<C> &A, cons
     using R = typename C::Real;
     R *p = reinterpret_cast<R *>(&A.p);
     int32_t *q = reinterpret_cast<int32_t *>(&A.i);
-    const int lane = threadIdx.x & 63;
-    for (int k = lane; k < Arena<C>::P_REALS; k += 64) p[k] = rec[k];
-    for (int k = lane; k < Arena<C>::I_INTS; k += 64) q[k] = irec[k];
+    const int lane = threadIdx.x & (C::VW - 1);
+    for (int k = lane; k < Arena<C>::P_REALS; k += C::VW) p[k] = rec[k];
+    for (int k = lane; k < Arena<C>::I_INTS; k += C::VW) q[k] = irec[k];
     RR_SYNC();
 }
 template <class C> __device__ __forceinline__ void store_record(const Arena<C> &A, typename C::Real *rec, int32_t *irec) {
     using R = typename C::Real;
     const R *p = reinterpret_cast<const R *>(&A.p);
     const int32_t *q = reinterpret_cast<const int32_t *>(&A.i);
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & (C::VW - 1);
     RR_SYNC();
-    for (int k = lane; k < Arena<C>::P_REALS; k += 64) rec[k] = p[k];
-    for (int k = lane; k < Arena<C>::I_INTS; k += 64) irec[k] = q[k];
+    for (int k = lane; k < Arena<C>::P_REALS; k += C::VW) rec[k] = p[k];
+    for (int k = lane; k < Arena<C>::I_INTS; k += C::VW) irec[k] = q[k];
 }
 
 constexpr int WAVES_PER_BLOCK = 4;
+template <class C> constexpr int arenas_per_block() { return 64 * WAVES_PER_BLOCK / C::VW; }
 #ifndef RR_MIN_WAVES_PER_SIMD
 #define RR_MIN_WAVES_PER_SIMD 4 // <=128 VGPRs: 4 waves/SIMD measured 4x faster than the 1 wave/SIMD the allocator picks unconstrained
 #endif
@@ -51,10 +55,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, RR_MIN_WAVES_PER_SIMD) void k
                                                               int32_t *irecs, int n, const int32_t *actions,
                                                               const float *thrust, int na, O *obs, O *reward,
                                                               uint8_t *done, O *obs_g, O *reward_g, int32_t *status) {
-    __shared__ Arena<C> lds[WAVES_PER_BLOCK];
-    const int wave = threadIdx.x >> 6;
-    const int arena = blockIdx.x * WAVES_PER_BLOCK + wave;
-    if (arena >= n) return; // wave-uniform; no workgroup barrier is ever used
+    __shared__ Arena<C> lds[arenas_per_block<C>()];
+    const int wave = threadIdx.x / C::VW; // virtual wave = arena slot in this workgroup
+    const int arena = blockIdx.x * arenas_per_block<C>() + wave;
+    if (arena >= n) return; // uniform per virtual wave; no workgroup barrier is ever used
     Arena<C> &A = lds[wave];
     typename C::Real *rec = recs + (size_t)arena * Arena<C>::P_STRIDE;
     int32_t *irec = irecs + (size_t)arena * Arena<C>::I_STRIDE;
@@ -73,20 +77,20 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_reset(SimParams<typena
                                                                int32_t *irecs, int n, const uint8_t *mask, int init,
                                                                O *obs, O *obs_g) {
     using R = typename C::Real;
-    __shared__ Arena<C> lds[WAVES_PER_BLOCK];
-    const int wave = threadIdx.x >> 6;
-    const int arena = blockIdx.x * WAVES_PER_BLOCK + wave;
+    __shared__ Arena<C> lds[arenas_per_block<C>()];
+    const int wave = threadIdx.x / C::VW; // virtual wave = arena slot in this workgroup
+    const int arena = blockIdx.x * arenas_per_block<C>() + wave;
     if (arena >= n) return;
     Arena<C> &A = lds[wave];
     R *rec = recs + (size_t)arena * Arena<C>::P_STRIDE;
     int32_t *irec = irecs + (size_t)arena * Arena<C>::I_STRIDE;
     int st = 0;
     if (init) { // Robot(team, (0,0)) / Ball(color, (0,0)) as built by GameEnv.__init__ (RR_EnvBase.py:85-109)
-        const int lane = threadIdx.x & 63;
+        const int lane = threadIdx.x & (C::VW - 1);
         R *p = reinterpret_cast<R *>(&A.p);
         int32_t *q = reinterpret_cast<int32_t *>(&A.i);
-        for (int k = lane; k < Arena<C>::P_REALS; k += 64) p[k] = (R)0;
-        for (int k = lane; k < Arena<C>::I_INTS; k += 64) q[k] = 0;
+        for (int k = lane; k < Arena<C>::P_REALS; k += C::VW) p[k] = (R)0;
+        for (int k = lane; k < Arena<C>::I_INTS; k += C::VW) q[k] = 0;
         RR_SYNC();
         if (lane < C::NR) robot_set_clean_lane(A, sp, lane, (R)0, (R)0, lane < C::NRH ? (R)90 : (R)-90);
         if (lane < C::NB) ball_set_clean_lane(A, lane, (R)0, (R)0, (R)0, (R)0);
@@ -101,8 +105,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_reset(SimParams<typena
     if (obs && doit) observe<C, O>(A, sp, 1, -1, -1, obs + (size_t)arena * 11, st);
     if (obs_g && doit) {
         if (!observe<C, O>(A, sp, -1, -1, -1, obs_g + (size_t)arena * 11, st)) {
-            const int lane = threadIdx.x & 63;
-            if (lane < 11) obs_g[(size_t)arena * 11 + lane] = (O)NAN;
+            for (int k = threadIdx.x & (C::VW - 1); k < 11; k += C::VW) obs_g[(size_t)arena * 11 + k] = (O)NAN;
         }
     }
     store_record(A, rec, irec);
@@ -112,17 +115,16 @@ template <class C, typename O>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_observe(SimParams<typename C::Real> sp, const typename C::Real *recs,
                                                                  const int32_t *irecs, int n, int team, int ridx, int bidx,
                                                                  O *obs) {
-    __shared__ Arena<C> lds[WAVES_PER_BLOCK];
-    const int wave = threadIdx.x >> 6;
-    const int arena = blockIdx.x * WAVES_PER_BLOCK + wave;
+    __shared__ Arena<C> lds[arenas_per_block<C>()];
+    const int wave = threadIdx.x / C::VW; // virtual wave = arena slot in this workgroup
+    const int arena = blockIdx.x * arenas_per_block<C>() + wave;
     if (arena >= n) return;
     Arena<C> &A = lds[wave];
     load_record(A, recs + (size_t)arena * Arena<C>::P_STRIDE, irecs + (size_t)arena * Arena<C>::I_STRIDE);
     derive(A, sp);
     int st = 0;
     if (!observe<C, O>(A, sp, team, ridx, bidx, obs + (size_t)arena * 11, st)) {
-        const int lane = threadIdx.x & 63;
-        if (lane < 11) obs[(size_t)arena * 11 + lane] = (O)NAN;
+        for (int k = threadIdx.x & (C::VW - 1); k < 11; k += C::VW) obs[(size_t)arena * 11 + k] = (O)NAN;
     }
 }
 
@@ -165,9 +167,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_set_poses(SimParams<ty
                                                                    int32_t *irecs, int n, const double *rxyr,
                                                                    const double *bxyv) {
     using R = typename C::Real;
-    __shared__ Arena<C> lds[WAVES_PER_BLOCK];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int arena = blockIdx.x * WAVES_PER_BLOCK + wave;
+    __shared__ Arena<C> lds[arenas_per_block<C>()];
+    const int wave = threadIdx.x / C::VW, lane = threadIdx.x & (C::VW - 1);
+    const int arena = blockIdx.x * arenas_per_block<C>() + wave;
     if (arena >= n) return;
     Arena<C> &A = lds[wave];
     R *rec = recs + (size_t)arena * Arena<C>::P_STRIDE;
@@ -199,14 +201,18 @@ __global__ void k_episode_stats(const typename C::Real *recs, const int32_t *ire
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-typedef Cfg<1, 0, 1, 0, double> CT64;
-typedef Cfg<2, 2, 4, 4, double> CG64;
-typedef Cfg<1, 0, 1, 0, float> CT32;
-typedef Cfg<2, 2, 4, 4, float> CG32;
+// Built configurations: (kind = shape + 2*dtype, entity counts, Real, VW).  The first VW listed for a kind is the
+// default; the environment variable RR_VW selects another built width (kernel tuning / A-B runs).
+#define RR_FOR_EACH_CFG(X)                                                                             \
+    X(0, 1, 0, 1, 0, double, 4) X(0, 1, 0, 1, 0, double, 8) X(0, 1, 0, 1, 0, double, 16) X(0, 1, 0, 1, 0, double, 64) \
+    X(1, 2, 2, 4, 4, double, 16) X(1, 2, 2, 4, 4, double, 32) X(1, 2, 2, 4, 4, double, 64)               \
+    X(2, 1, 0, 1, 0, float, 4) X(2, 1, 0, 1, 0, float, 8) X(2, 1, 0, 1, 0, float, 16) X(2, 1, 0, 1, 0, float, 64)     \
+    X(3, 2, 2, 4, 4, float, 16) X(3, 2, 2, 4, 4, float, 32) X(3, 2, 2, 4, 4, float, 64)
 
 struct rr_env {
     rr_config cfg;
     int kind; // 0 T64, 1 G64, 2 T32, 3 G32
+    int vw;   // lanes per arena
     void *recs;
     int32_t *irecs;
     size_t rec_bytes, irec_bytes;
@@ -235,17 +241,19 @@ template <typename R> static void fill_params(SimParams<R> &sp, const rr_config 
     sp.game_len = c.game_len_steps; sp.game_mode = c.game_mode; sp.time_limit = c.time_limit; sp.auto_reset = c.auto_reset;
     sp.seed = c.seed; sp.arena_offset = c.arena_offset;
 }
+template <typename R> static const SimParams<R> &params_of(const rr_env *e);
+template <> const SimParams<double> &params_of<double>(const rr_env *e) { return e->spd; }
+template <> const SimParams<float> &params_of<float>(const rr_env *e) { return e->spf; }
 
-#define RR_DISPATCH(env, ...)                                                                              \
-    switch ((env)->kind) {                                                                                 \
-    case 0: { typedef CT64 CC; typedef double RR; RR *recs = (RR *)(env)->recs; const SimParams<RR> &sp = (env)->spd; (void)recs; (void)sp; __VA_ARGS__; } break; \
-    case 1: { typedef CG64 CC; typedef double RR; RR *recs = (RR *)(env)->recs; const SimParams<RR> &sp = (env)->spd; (void)recs; (void)sp; __VA_ARGS__; } break; \
-    case 2: { typedef CT32 CC; typedef float RR; RR *recs = (RR *)(env)->recs; const SimParams<RR> &sp = (env)->spf; (void)recs; (void)sp; __VA_ARGS__; } break;  \
-    case 3: { typedef CG32 CC; typedef float RR; RR *recs = (RR *)(env)->recs; const SimParams<RR> &sp = (env)->spf; (void)recs; (void)sp; __VA_ARGS__; } break;  \
-    default: return fail(-1, "corrupt handle");                                                           \
-    }
-
-static inline dim3 wave_grid(int n) { return dim3((unsigned)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)); }
+// calls f(Cfg<...>{}) for the configuration the handle was created with
+template <class F> static int dispatch(const rr_env *e, F &&f) {
+#define X(kind_, a, b, c, d, R_, vw_) \
+    if (e->kind == kind_ && e->vw == vw_) return f(Cfg<a, b, c, d, R_, vw_>{});
+    RR_FOR_EACH_CFG(X)
+#undef X
+    return fail(-1, "corrupt handle");
+}
+template <class C> static dim3 arena_grid(int n) { return dim3((unsigned)((n + arenas_per_block<C>() - 1) / arenas_per_block<C>())); }
 static inline dim3 wave_block() { return dim3(64 * WAVES_PER_BLOCK); }
 
 extern "C" {
@@ -273,15 +281,18 @@ int rr_create(const rr_config *cfg, rr_env **out) {
     if (!e) return fail(-3, "rr_create: out of host memory");
     e->cfg = *cfg;
     e->kind = shape + 2 * (cfg->dtype == RR_DTYPE_F32 ? 1 : 0);
+    e->vw = 0;
+    const char *want = getenv("RR_VW");
+    const int want_vw = want ? atoi(want) : 0;
+#define X(kind_, a, b, c, d, R_, vw_) \
+    if (e->kind == kind_ && (e->vw == 0 || want_vw == vw_)) e->vw = vw_;
+    RR_FOR_EACH_CFG(X)
+#undef X
     fill_params(e->spd, *cfg);
     fill_params(e->spf, *cfg);
-    size_t pstride = 0, istride = 0, rsz = cfg->dtype == RR_DTYPE_F32 ? 4 : 8;
-    switch (e->kind) {
-    case 0: pstride = Arena<CT64>::P_STRIDE; istride = Arena<CT64>::I_STRIDE; break;
-    case 1: pstride = Arena<CG64>::P_STRIDE; istride = Arena<CG64>::I_STRIDE; break;
-    case 2: pstride = Arena<CT32>::P_STRIDE; istride = Arena<CT32>::I_STRIDE; break;
-    default: pstride = Arena<CG32>::P_STRIDE; istride = Arena<CG32>::I_STRIDE; break;
-    }
+    size_t pstride = 0, istride = 0;
+    const size_t rsz = cfg->dtype == RR_DTYPE_F32 ? 4 : 8;
+    dispatch(e, [&](auto c) { using CC = decltype(c); pstride = Arena<CC>::P_STRIDE; istride = Arena<CC>::I_STRIDE; return 0; });
     e->rec_bytes = pstride * rsz;
     e->irec_bytes = istride * 4;
     hipError_t he = hipMalloc(&e->recs, e->rec_bytes * (size_t)cfg->num_envs);
@@ -293,8 +304,12 @@ int rr_create(const rr_config *cfg, rr_env **out) {
     }
     // constructor placement (RR_EnvBase.py:111-116): episode 0 of the counter RNG
     const int n = cfg->num_envs;
-    RR_DISPATCH(e, hipLaunchKernelGGL((k_reset<CC, float>), wave_grid(n), wave_block(), 0, 0, sp, recs, e->irecs, n,
-                                      (const uint8_t *)nullptr, 1, (float *)nullptr, (float *)nullptr));
+    dispatch(e, [&](auto c) {
+        using CC = decltype(c); using RR = typename CC::Real;
+        hipLaunchKernelGGL((k_reset<CC, float>), arena_grid<CC>(n), wave_block(), 0, 0, params_of<RR>(e), (RR *)e->recs,
+                           e->irecs, n, (const uint8_t *)nullptr, 1, (float *)nullptr, (float *)nullptr);
+        return 0;
+    });
     he = hipGetLastError();
     if (he == hipSuccess) he = hipDeviceSynchronize();
     if (he != hipSuccess) {
@@ -318,8 +333,13 @@ int rr_destroy(rr_env *e) {
 int rr_reset(rr_env *e, const uint8_t *mask, float *obs, float *obs_g, void *stream) {
     if (!e) return fail(-1, "rr_reset: null handle");
     const int n = e->cfg.num_envs;
-    RR_DISPATCH(e, hipLaunchKernelGGL((k_reset<CC, float>), wave_grid(n), wave_block(), 0, (hipStream_t)stream, sp, recs,
-                                      e->irecs, n, mask, 0, obs, obs_g));
+    int rc = dispatch(e, [&](auto c) {
+        using CC = decltype(c); using RR = typename CC::Real;
+        hipLaunchKernelGGL((k_reset<CC, float>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
+                           (RR *)e->recs, e->irecs, n, mask, 0, obs, obs_g);
+        return 0;
+    });
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -337,9 +357,14 @@ int rr_step(rr_env *e, const int32_t *actions, int32_t na, float *obs, float *re
             float *reward_g, int32_t *status, void *stream) {
     if (int rc = check_step_args(e, actions, na, obs, reward, done)) return rc;
     const int n = e->cfg.num_envs;
-    RR_DISPATCH(e, hipLaunchKernelGGL((k_step<CC, float>), wave_grid(n), wave_block(), 0, (hipStream_t)stream, sp, recs,
-                                      e->irecs, n, actions, (const float *)nullptr, (int)na, obs, reward, done, obs_g,
-                                      reward_g, status));
+    int rc = dispatch(e, [&](auto c) {
+        using CC = decltype(c); using RR = typename CC::Real;
+        hipLaunchKernelGGL((k_step<CC, float>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
+                           (RR *)e->recs, e->irecs, n, actions, (const float *)nullptr, (int)na, obs, reward, done, obs_g,
+                           reward_g, status);
+        return 0;
+    });
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -348,9 +373,14 @@ int rr_step_thrust(rr_env *e, const float *thrust, int32_t nk, float *obs, float
                    float *reward_g, int32_t *status, void *stream) {
     if (int rc = check_step_args(e, thrust, nk, obs, reward, done)) return rc;
     const int n = e->cfg.num_envs;
-    RR_DISPATCH(e, hipLaunchKernelGGL((k_step<CC, float>), wave_grid(n), wave_block(), 0, (hipStream_t)stream, sp, recs,
-                                      e->irecs, n, (const int32_t *)nullptr, thrust, (int)nk, obs, reward, done, obs_g,
-                                      reward_g, status));
+    int rc = dispatch(e, [&](auto c) {
+        using CC = decltype(c); using RR = typename CC::Real;
+        hipLaunchKernelGGL((k_step<CC, float>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
+                           (RR *)e->recs, e->irecs, n, (const int32_t *)nullptr, thrust, (int)nk, obs, reward, done, obs_g,
+                           reward_g, status);
+        return 0;
+    });
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -359,41 +389,56 @@ int rr_step_f64(rr_env *e, const int32_t *actions, int32_t na, double *obs, doub
                 double *reward_g, int32_t *status, void *stream) {
     if (int rc = check_step_args(e, actions, na, obs, reward, done)) return rc;
     const int n = e->cfg.num_envs;
-    hipStream_t s = (hipStream_t)stream;
-    switch (e->kind) {
-    case 0: hipLaunchKernelGGL((k_step<CT64, double>), wave_grid(n), wave_block(), 0, s, e->spd, (double *)e->recs, e->irecs, n,
-                               actions, (const float *)nullptr, (int)na, obs, reward, done, obs_g, reward_g, status); break;
-    case 1: hipLaunchKernelGGL((k_step<CG64, double>), wave_grid(n), wave_block(), 0, s, e->spd, (double *)e->recs, e->irecs, n,
-                               actions, (const float *)nullptr, (int)na, obs, reward, done, obs_g, reward_g, status); break;
-    default: return fail(-1, "rr_step_f64: handle was created with RR_DTYPE_F32");
-    }
+    int rc = dispatch(e, [&](auto c) {
+        using CC = decltype(c); using RR = typename CC::Real;
+        if constexpr (std::is_same<RR, double>::value) {
+            hipLaunchKernelGGL((k_step<CC, double>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
+                               (RR *)e->recs, e->irecs, n, actions, (const float *)nullptr, (int)na, obs, reward, done,
+                               obs_g, reward_g, status);
+            return 0;
+        } else {
+            return fail(-1, "rr_step_f64: handle was created with RR_DTYPE_F32");
+        }
+    });
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-int rr_observe(rr_env *e, int32_t team, int32_t ridx, int32_t bidx, float *obs, void *stream) {
+static int check_obs_args(rr_env *e, const void *obs, int32_t team, int32_t ridx, int32_t bidx) {
     if (!e || !obs) return fail(-1, "rr_observe: null argument");
     const int nr = e->cfg.nr_happy + e->cfg.nr_grumpy, nb = e->cfg.nb_pos + e->cfg.nb_neg;
     if ((team != 1 && team != -1) || ridx >= nr || bidx >= nb) return fail(-1, "rr_observe: bad team/robot/ball index");
+    return 0;
+}
+int rr_observe(rr_env *e, int32_t team, int32_t ridx, int32_t bidx, float *obs, void *stream) {
+    if (int rc = check_obs_args(e, obs, team, ridx, bidx)) return rc;
     const int n = e->cfg.num_envs;
-    RR_DISPATCH(e, hipLaunchKernelGGL((k_observe<CC, float>), wave_grid(n), wave_block(), 0, (hipStream_t)stream, sp, recs,
-                                      e->irecs, n, (int)team, (int)ridx, (int)bidx, obs));
+    int rc = dispatch(e, [&](auto c) {
+        using CC = decltype(c); using RR = typename CC::Real;
+        hipLaunchKernelGGL((k_observe<CC, float>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
+                           (const RR *)e->recs, (const int32_t *)e->irecs, n, (int)team, (int)ridx, (int)bidx, obs);
+        return 0;
+    });
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
 }
 int rr_observe_f64(rr_env *e, int32_t team, int32_t ridx, int32_t bidx, double *obs, void *stream) {
-    if (!e || !obs) return fail(-1, "rr_observe_f64: null argument");
-    const int nr = e->cfg.nr_happy + e->cfg.nr_grumpy, nb = e->cfg.nb_pos + e->cfg.nb_neg;
-    if ((team != 1 && team != -1) || ridx >= nr || bidx >= nb) return fail(-1, "rr_observe_f64: bad team/robot/ball index");
+    if (int rc = check_obs_args(e, obs, team, ridx, bidx)) return rc;
     const int n = e->cfg.num_envs;
-    hipStream_t s = (hipStream_t)stream;
-    switch (e->kind) {
-    case 0: hipLaunchKernelGGL((k_observe<CT64, double>), wave_grid(n), wave_block(), 0, s, e->spd, (double *)e->recs, e->irecs,
-                               n, (int)team, (int)ridx, (int)bidx, obs); break;
-    case 1: hipLaunchKernelGGL((k_observe<CG64, double>), wave_grid(n), wave_block(), 0, s, e->spd, (double *)e->recs, e->irecs,
-                               n, (int)team, (int)ridx, (int)bidx, obs); break;
-    default: return fail(-1, "rr_observe_f64: handle was created with RR_DTYPE_F32");
-    }
+    int rc = dispatch(e, [&](auto c) {
+        using CC = decltype(c); using RR = typename CC::Real;
+        if constexpr (std::is_same<RR, double>::value) {
+            hipLaunchKernelGGL((k_observe<CC, double>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream,
+                               params_of<RR>(e), (const RR *)e->recs, (const int32_t *)e->irecs, n, (int)team, (int)ridx,
+                               (int)bidx, obs);
+            return 0;
+        } else {
+            return fail(-1, "rr_observe_f64: handle was created with RR_DTYPE_F32");
+        }
+    });
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -401,38 +446,64 @@ int rr_observe_f64(rr_env *e, int32_t team, int32_t ridx, int32_t bidx, double *
 int rr_set_state(rr_env *e, const double *robots, const int32_t *ri, const double *balls, const int32_t *step, void *stream) {
     if (!e || !robots || !ri || !balls || !step) return fail(-1, "rr_set_state: null argument");
     const int n = e->cfg.num_envs;
-    RR_DISPATCH(e, hipLaunchKernelGGL((k_set_state<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, recs,
-                                      e->irecs, n, robots, ri, balls, step));
+    int rc = dispatch(e, [&](auto c) {
+        using CC = decltype(c); using RR = typename CC::Real;
+        hipLaunchKernelGGL((k_set_state<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (RR *)e->recs, e->irecs,
+                           n, robots, ri, balls, step);
+        return 0;
+    });
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
 }
 int rr_get_state(rr_env *e, double *robots, int32_t *ri, double *balls, int32_t *step, void *stream) {
     if (!e || !robots || !ri || !balls || !step) return fail(-1, "rr_get_state: null argument");
     const int n = e->cfg.num_envs;
-    RR_DISPATCH(e, hipLaunchKernelGGL((k_get_state<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream,
-                                      (const RR *)recs, (const int32_t *)e->irecs, n, robots, ri, balls, step));
+    int rc = dispatch(e, [&](auto c) {
+        using CC = decltype(c); using RR = typename CC::Real;
+        hipLaunchKernelGGL((k_get_state<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const RR *)e->recs,
+                           (const int32_t *)e->irecs, n, robots, ri, balls, step);
+        return 0;
+    });
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
 }
 int rr_set_poses(rr_env *e, const double *rxyr, const double *bxyv, void *stream) {
     if (!e || !rxyr || !bxyv) return fail(-1, "rr_set_poses: null argument");
     const int n = e->cfg.num_envs;
-    RR_DISPATCH(e, hipLaunchKernelGGL((k_set_poses<CC>), wave_grid(n), wave_block(), 0, (hipStream_t)stream, sp, recs,
-                                      e->irecs, n, rxyr, bxyv));
+    int rc = dispatch(e, [&](auto c) {
+        using CC = decltype(c); using RR = typename CC::Real;
+        hipLaunchKernelGGL((k_set_poses<CC>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
+                           (RR *)e->recs, e->irecs, n, rxyr, bxyv);
+        return 0;
+    });
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
 }
 int rr_episode_stats(rr_env *e, float *lr, float *lrg, int32_t *ll, int32_t *cnt, void *stream) {
     if (!e) return fail(-1, "rr_episode_stats: null handle");
     const int n = e->cfg.num_envs;
-    RR_DISPATCH(e, hipLaunchKernelGGL((k_episode_stats<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream,
-                                      (const RR *)recs, (const int32_t *)e->irecs, n, lr, lrg, ll, cnt));
+    int rc = dispatch(e, [&](auto c) {
+        using CC = decltype(c); using RR = typename CC::Real;
+        hipLaunchKernelGGL((k_episode_stats<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const RR *)e->recs,
+                           (const int32_t *)e->irecs, n, lr, lrg, ll, cnt);
+        return 0;
+    });
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
 }
 int rr_state_bytes_per_env(const rr_env *e, int64_t *bytes) {
     if (!e || !bytes) return fail(-1, "rr_state_bytes_per_env: null argument");
     *bytes = (int64_t)(e->rec_bytes + e->irec_bytes);
+    return 0;
+}
+
+int rr_lanes_per_env(const rr_env *e, int32_t *lanes) {
+    if (!e || !lanes) return fail(-1, "rr_lanes_per_env: null argument");
+    *lanes = e->vw;
     return 0;
 }
 

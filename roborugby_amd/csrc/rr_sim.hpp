@@ -42,8 +42,13 @@
 #define RR_HDN
 #endif
 
+// A wavefront is split into 64/VW "virtual waves" of VW lanes (C::VW, a power of two); each owns one arena.
+// Everything below is ordinary SIMT code in which `l` is the lane's index inside its virtual wave: control flow
+// is uniform inside a virtual wave by construction (it only depends on that arena's ballots and LDS), so its
+// lanes stay converged, while different virtual waves of one wavefront may diverge on the rare response paths.
+// VW = 64 is the plain one-wavefront-per-arena mapping; smaller VW packs several small arenas per wavefront.
 #if RR_GPU
-#define RR_LANE_ID() ((int)(threadIdx.x & 63))
+#define RR_LANE_ID() ((int)(threadIdx.x & (C::VW - 1)))
 #define RR_FOR_LANES(l) for (int l = RR_LANE_ID(), l##_o = 0; l##_o < 1; ++l##_o)
 #define RR_IS_LANE0 (RR_LANE_ID() == 0)
 // LDS is only shared inside the wave: a wavefront-scope release/acquire pair orders it
@@ -53,15 +58,25 @@
         __builtin_amdgcn_wave_barrier();                             \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
     } while (0)
-#define RR_VOTE(mask, l, pred) (mask) = __ballot(pred)
+// ballot restricted to this lane's virtual wave (inactive / diverged lanes contribute 0)
+#define RR_VOTE(mask, l, pred) (mask) = rr::vballot<C::VW>(pred)
 #else
-#define RR_FOR_LANES(l) for (int l = 0; l < 64; ++l)
+#define RR_FOR_LANES(l) for (int l = 0; l < C::VW; ++l)
 #define RR_IS_LANE0 true
 #define RR_SYNC() do { } while (0)
 #define RR_VOTE(mask, l, pred) (mask) |= ((uint64_t)((pred) ? 1 : 0)) << (l)
 #endif
 
 namespace rr {
+
+#if RR_GPU
+template <int VW> __device__ __forceinline__ uint64_t vballot(bool pred) {
+    uint64_t m = __ballot(pred);
+    if (VW == 64) return m;
+    const int sh = (int)(threadIdx.x & 63 & ~(VW - 1));
+    return (m >> sh) & ((1ull << (VW & 63)) - 1ull);
+}
+#endif
 
 enum : int {
     ST_BOT_RESOLVE_FAIL = 1, ST_BOT_STUCK = 2, ST_UNDO_MOVE_FAIL = 4, ST_UNDO_FAIL = 8, ST_SAME_SPOT = 16,
@@ -191,15 +206,17 @@ template <typename R> RR_HD R angle_degrees(V2<R> a, V2<R> b, int &st) {
 }
 
 // ------------------------------------------------------------------------------------------------ config
-template <int NRH_, int NRG_, int NBP_, int NBN_, typename Real_> struct Cfg {
+template <int NRH_, int NRG_, int NBP_, int NBN_, typename Real_, int VW_ = 64> struct Cfg {
     static constexpr int NRH = NRH_, NRG = NRG_, NBP = NBP_, NBN = NBN_;
     static constexpr int NR = NRH_ + NRG_, NB = NBP_ + NBN_;
     static constexpr int NPR = NR * (NR - 1) / 2; // robot pairs
     static constexpr int NPB = NB * (NB - 1) / 2; // ball pairs
+    static constexpr int VW = VW_;                // lanes per arena (virtual wave width)
     using Real = Real_;
-    static_assert(NR >= 1 && NR <= 5, "lidar lane mapping needs 12*NR <= 64");
-    static_assert(NB >= 1 && NB * NR <= 32, "ball x robot x diameter tasks must fit 64 lanes");
-    static_assert(NPB <= 64, "ball pairs must fit one wave");
+    static_assert(VW == 2 || VW == 4 || VW == 8 || VW == 16 || VW == 32 || VW == 64, "VW must divide the wavefront");
+    static_assert(NR >= 1 && NR <= VW && NB >= 1 && NB <= VW, "one lane per entity");
+    static_assert(NPR == 0 || VW >= 16, "robot-pair tasks come in groups of 16 (side x side)");
+    static_assert(NB * NR <= 32 && NPB <= 64, "pair masks are 32/64-bit");
 };
 
 template <typename R> struct SimParams {
@@ -232,16 +249,17 @@ template <class C> struct Arena {
     } i;
     // ---- per-step scratch
     R rel[NR][8];   // corner offsets TL,TR,BL,BR (x,y) for the current rotation
-    R irel[NR][8];  // corner offsets of the ball's inner square at rot+45 (diameter end points)
     R irot[NR];     // rotation irel was built for (NaN = stale)
     R sm[NR][4], sc[NR][4]; // slope / y-intercept of the four sides (get_slope_yint, MyUtils.py:44-58) for the current pose
-    R ax[NR], ay[NR], arot[NR], arel[NR][8]; // pose at frame begin (= ring entry written this frame)
-    R prel[NR][8];  // corner offsets for the persisted previous-move pose (px,py,prot)
+    R ax[NR], ay[NR], arot[NR]; // pose at frame begin (= ring entry written this frame)
     R psx[NR], psy[NR]; // robot centre at step begin (rectDblPriorStep)
     R bfx[NB], bfy[NB], pfx[NB], pfy[NB];
     int32_t bmass[NB];
-    R lf[3 * 4 * NR], lb[3 * 4 * NR]; // lidar candidates
-    R lid[6];                          // capped minima: front/back per ray
+    union { // the lidar candidates are only alive inside observe(), the inner-square offsets only inside a sub-step
+        R irel[NR][8];                    // corner offsets of the ball's inner square at rot+45 (diameter end points)
+        R lidar[2][3 * NR];               // [front|back][ray, rect] minima over the rect's four sides
+    } u;
+    R lid[6];                             // capped minima: front/back per ray
     static constexpr int P_REALS = (int)(sizeof(P) / sizeof(R));
     static constexpr int I_INTS = (int)(sizeof(I) / sizeof(int32_t));
     static constexpr int P_STRIDE = (P_REALS + 15) / 16 * 16; // record strides in HBM (128-B multiples)
@@ -387,17 +405,12 @@ template <class C> RR_HD void robot_move_lane(Arena<C> &A, const SimParams<typen
     store_robot(A, r, f);
 }
 // Robot.undo_move (RR_Robot.py:110-137): back to the pose stored at frame begin
-template <class C> RR_HD void robot_undo_lane(Arena<C> &A, int r) {
+template <class C> RR_HD void robot_undo_lane(Arena<C> &A, const SimParams<typename C::Real> &sp, int r) {
     using R = typename C::Real;
     FR<R> f = load_robot(A, r);
     fr_set_cx<R>(f, A.ax[r]);
     fr_set_cy<R>(f, A.ay[r]);
-    R nr = py_mod<R>(A.arot[r] + (R)720, (R)360);
-    if (nr != f.rot) {
-        f.rot = nr;
-        for (int k = 0; k < 8; k++) f.rel[k] = A.arel[r][k];
-        fr_edges_from_rel<R>(f);
-    }
+    fr_set_rot<R>(f, A.arot[r], sp.rob_cdist); // no-op unless the undone move rotated (rare path: trig is fine here)
     store_robot(A, r, f);
     A.i.mc[r] -= 1;
 }
@@ -407,19 +420,22 @@ template <class C> RR_HD void refresh_inner_lane(Arena<C> &A, const SimParams<ty
     R rot = A.p.rrot[r];
     if (A.irot[r] == rot) return;
     A.irot[r] = rot;
-    corners_for<R>(py_mod<R>(rot + (R)45 + (R)720, (R)360), sp.inner_h, sp.inner_h, sp.inner_cdist, A.irel[r]);
+    corners_for<R>(py_mod<R>(rot + (R)45 + (R)720, (R)360), sp.inner_h, sp.inner_h, sp.inner_cdist, A.u.irel[r]);
 }
 
 // side slope/intercept cache: one lane per (robot, side); must follow every robot pose change
 template <class C> RR_HD void refresh_sides(Arena<C> &A) {
     using R = typename C::Real;
-    RR_FOR_LANES(l) {
-        if (l < 4 * C::NR) {
-            int r = l >> 2, sd = l & 3, st = 0;
-            Seg<R> g = robot_side(A, r, sd);
-            R m, c;
-            slope_yint<R>(g.a, g.b, m, c, st);
-            A.sm[r][sd] = m; A.sc[r][sd] = c;
+    for (int base = 0; base < 4 * C::NR; base += C::VW) {
+        RR_FOR_LANES(l) {
+            int t = base + l;
+            if (t < 4 * C::NR) {
+                int r = t >> 2, sd = t & 3, st = 0;
+                Seg<R> g = robot_side(A, r, sd);
+                R m, c;
+                slope_yint<R>(g.a, g.b, m, c, st);
+                A.sm[r][sd] = m; A.sc[r][sd] = c;
+            }
         }
     }
     RR_SYNC();
@@ -443,7 +459,7 @@ template <class C> RR_HD uint32_t detect_robot_pairs(const Arena<C> &A) {
     using R = typename C::Real;
     uint32_t pairs = 0;
     constexpr int NT = C::NPR * 16;
-    for (int base = 0; base < NT; base += 64) {
+    for (int base = 0; base < NT; base += C::VW) {
         uint64_t m = 0;
         RR_FOR_LANES(l) {
             bool hit = false;
@@ -461,7 +477,7 @@ template <class C> RR_HD uint32_t detect_robot_pairs(const Arena<C> &A) {
             }
             RR_VOTE(m, l, hit);
         }
-        for (int q = 0; q < 4; q++)
+        for (int q = 0; q < C::VW / 16; q++)
             if ((m >> (16 * q)) & 0xFFFFull) pairs |= 1u << ((base >> 4) + q);
     }
     return pairs;
@@ -471,64 +487,81 @@ template <class C> RR_HD uint32_t detect_robot_pairs(const Arena<C> &A) {
 template <class C> RR_HD uint32_t detect_ball_robot(Arena<C> &A, const SimParams<typename C::Real> &sp) {
     using R = typename C::Real;
     constexpr int NT = C::NB * C::NR * 2;
-    uint64_t close = 0;
-    RR_FOR_LANES(l) {
-        bool c = false;
-        if (l < NT) {
-            int pr = l >> 1, r = pr % C::NR, b = pr / C::NR;
-            R dx = A.p.bcx[b] - A.p.rcx[r], dy = A.p.bcy[b] - A.p.rcy[r];
-            c = dx * dx + dy * dy <= cull_br2<R>();
+    constexpr int NROUND = (NT + C::VW - 1) / C::VW;
+    uint64_t close[NROUND];
+    bool any = false;
+    for (int k = 0; k < NROUND; k++) {
+        uint64_t cm = 0;
+        RR_FOR_LANES(l) {
+            bool c = false;
+            int t = k * C::VW + l;
+            if (t < NT) {
+                int pr = t >> 1, r = pr % C::NR, b = pr / C::NR;
+                R dx = A.p.bcx[b] - A.p.rcx[r], dy = A.p.bcy[b] - A.p.rcy[r];
+                c = dx * dx + dy * dy <= cull_br2<R>();
+            }
+            RR_VOTE(cm, l, c);
         }
-        RR_VOTE(close, l, c);
+        close[k] = cm;
+        any = any | (cm != 0);
     }
-    if (!close) return 0;
+    if (!any) return 0;
     // narrow phase: the inner-square corner offsets (rot+45) are only needed now
     RR_FOR_LANES(l) {
         if (l < C::NR) refresh_inner_lane(A, sp, l);
     }
     RR_SYNC();
-    uint64_t m = 0;
-    RR_FOR_LANES(l) {
-        bool hit = false;
-        if ((close >> l) & 1) {
-            int d = l & 1, pr = l >> 1, r = pr % C::NR, b = pr / C::NR, st = 0;
-            V2<R> bc = { A.p.bcx[b], A.p.bcy[b] };
-            hit = (dist<R>(robot_corner(A, r, 2 * d), bc) < (R)7) | (dist<R>(robot_corner(A, r, 2 * d + 1), bc) < (R)7);
-            // diameters (TL->BR) and (TR->BL) of the inner square
-            int ca = d == 0 ? TL : TR, cb = d == 0 ? BR : BL;
-            Seg<R> dia = { { bc.x + A.irel[r][2 * ca], bc.y + A.irel[r][2 * ca + 1] },
-                           { bc.x + A.irel[r][2 * cb], bc.y + A.irel[r][2 * cb + 1] } };
-            R md, cd;
-            slope_yint<R>(dia.a, dia.b, md, cd, st);
-            for (int sd = 0; sd < 4; sd++) {
-                Seg<R> side = robot_side(A, r, sd);
-                V2<R> p = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, md, cd, dia.a.x);
-                hit = hit | (within<R>(p, side, (R)0) & within<R>(p, dia, (R)0));
-            }
-        }
-        RR_VOTE(m, l, hit);
-    }
     uint32_t pairs = 0;
-    for (int q = 0; q < C::NB * C::NR; q++)
-        if ((m >> (2 * q)) & 3ull) pairs |= 1u << q;
+    for (int k = 0; k < NROUND; k++) {
+        if (!close[k]) continue;
+        uint64_t m = 0;
+        RR_FOR_LANES(l) {
+            bool hit = false;
+            if ((close[k] >> l) & 1) {
+                int t = k * C::VW + l;
+                int d = t & 1, pr = t >> 1, r = pr % C::NR, b = pr / C::NR, st = 0;
+                V2<R> bc = { A.p.bcx[b], A.p.bcy[b] };
+                hit = (dist<R>(robot_corner(A, r, 2 * d), bc) < (R)7) | (dist<R>(robot_corner(A, r, 2 * d + 1), bc) < (R)7);
+                // diameters (TL->BR) and (TR->BL) of the inner square
+                int ca = d == 0 ? TL : TR, cb = d == 0 ? BR : BL;
+                Seg<R> dia = { { bc.x + A.u.irel[r][2 * ca], bc.y + A.u.irel[r][2 * ca + 1] },
+                               { bc.x + A.u.irel[r][2 * cb], bc.y + A.u.irel[r][2 * cb + 1] } };
+                R md, cd;
+                slope_yint<R>(dia.a, dia.b, md, cd, st);
+                for (int sd = 0; sd < 4; sd++) {
+                    Seg<R> side = robot_side(A, r, sd);
+                    V2<R> p = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, md, cd, dia.a.x);
+                    hit = hit | (within<R>(p, side, (R)0) & within<R>(p, dia, (R)0));
+                }
+            }
+            RR_VOTE(m, l, hit);
+        }
+        for (int q = 0; q < C::VW / 2; q++)
+            if ((m >> (2 * q)) & 3ull) pairs |= 1u << (k * (C::VW / 2) + q);
+    }
     return pairs;
 }
 // balls_collided (RR_TrashyPhysics.py:72-73): one lane per ball pair
 template <class C> RR_HD uint64_t detect_ball_pairs(const Arena<C> &A) {
     using R = typename C::Real;
-    uint64_t m = 0;
+    uint64_t mask = 0;
     if (C::NPB == 0) return 0;
-    RR_FOR_LANES(l) {
-        bool hit = false;
-        if (l < C::NPB) {
-            int i, j;
-            pair_of<C>(l, C::NB, i, j);
-            V2<R> a = { A.p.bcx[i], A.p.bcy[i] }, b = { A.p.bcx[j], A.p.bcy[j] };
-            hit = dist<R>(a, b) <= (R)14;
+    for (int base = 0; base < C::NPB; base += C::VW) {
+        uint64_t m = 0;
+        RR_FOR_LANES(l) {
+            bool hit = false;
+            int t = base + l;
+            if (t < C::NPB) {
+                int i, j;
+                pair_of<C>(t, C::NB, i, j);
+                V2<R> a = { A.p.bcx[i], A.p.bcy[i] }, b = { A.p.bcx[j], A.p.bcy[j] };
+                hit = dist<R>(a, b) <= (R)14;
+            }
+            RR_VOTE(m, l, hit);
         }
-        RR_VOTE(m, l, hit);
+        mask |= m << base;
     }
-    return m;
+    return mask;
 }
 // collided_wall on the int-truncated rect (RR_TrashyPhysics.py:76-85, RR_Ball.py:8-15)
 template <class C> RR_HD bool ball_collided_wall(const Arena<C> &A, const SimParams<typename C::Real> &sp, int b) {
@@ -546,22 +579,27 @@ template <class C> RR_HD uint32_t detect_ball_wall(const Arena<C> &A, const SimP
 }
 
 // ------------------------------------------------------------------------------------------------ contact responses (wave-uniform, list order)
-// rectDblPriorFrame (RR_Robot.py:43-58): pose at the start of the robot's last move that was not undone
+// rectDblPriorFrame (RR_Robot.py:43-58): pose at the start of the robot's last move that was not undone.  Only the
+// (rare) contact responses need its corners, so they are rebuilt here on demand exactly like the reference does
+// (`rectPrior.rotation = rot` re-runs the rotation setter on (rot+720)%360).
 template <class C>
-RR_HD void robot_prev_frame(const Arena<C> &A, int r, uint32_t bots_moved, typename C::Real &x, typename C::Real &y,
-                            const typename C::Real *&rel) {
-    if (bots_moved & (1u << r)) { x = A.ax[r]; y = A.ay[r]; rel = A.arel[r]; }
-    else if (!is_nan(A.p.px[r])) { x = A.p.px[r]; y = A.p.py[r]; rel = A.prel[r]; }
-    else { x = A.p.rcx[r]; y = A.p.rcy[r]; rel = A.rel[r]; }
+RR_HD void robot_prev_frame(const Arena<C> &A, const SimParams<typename C::Real> &sp, int r, uint32_t bots_moved,
+                            typename C::Real &x, typename C::Real &y, typename C::Real *rel) {
+    using R = typename C::Real;
+    R rot;
+    if (bots_moved & (1u << r)) { x = A.ax[r]; y = A.ay[r]; rot = A.arot[r]; }
+    else if (!is_nan(A.p.px[r])) { x = A.p.px[r]; y = A.p.py[r]; rot = A.p.prot[r]; }
+    else { x = A.p.rcx[r]; y = A.p.rcy[r]; rot = A.p.rrot[r]; }
+    corners_for<R>(py_mod<R>(rot + (R)720, (R)360), (R)10, (R)20, sp.rob_cdist, rel);
 }
 template <class C> RR_HD void force_diameters(const Arena<C> &A, int r, V2<typename C::Real> bc, Seg<typename C::Real> dia[2]) {
     // (BL->TR) and (BR->TL), RR_TrashyPhysics.py:95-104
-    const typename C::Real *q = A.irel[r];
+    const typename C::Real *q = A.u.irel[r];
     dia[0].a = { bc.x + q[2 * BL], bc.y + q[2 * BL + 1] }; dia[0].b = { bc.x + q[2 * TR], bc.y + q[2 * TR + 1] };
     dia[1].a = { bc.x + q[2 * BR], bc.y + q[2 * BR + 1] }; dia[1].b = { bc.x + q[2 * TL], bc.y + q[2 * TL + 1] };
 }
 // apply_force_to_ball (RR_TrashyPhysics.py:88-152)
-template <class C> RR_HDN void apply_force_to_ball(Arena<C> &A, int r, int b, uint32_t bots_moved, int &st) {
+template <class C> RR_HDN void apply_force_to_ball(Arena<C> &A, const SimParams<typename C::Real> &sp, int r, int b, uint32_t bots_moved, int &st) {
     using R = typename C::Real;
     const R cbuf = (R).5;
     V2<R> bc = { A.p.bcx[b], A.p.bcy[b] }, rc = { A.p.rcx[r], A.p.rcy[r] };
@@ -585,8 +623,8 @@ template <class C> RR_HDN void apply_force_to_ball(Arena<C> &A, int r, int b, ui
         }
     }
     if (!done) {
-        R px, py; const R *prel;
-        robot_prev_frame(A, r, bots_moved, px, py, prel);
+        R px, py, prel[8];
+        robot_prev_frame(A, sp, r, bots_moved, px, py, prel);
         #pragma unroll 1
         for (int c = 0; c < 4 && !done; c++) {
             V2<R> bcn = robot_corner(A, r, c);
@@ -616,7 +654,7 @@ template <typename R> RR_HD void bounce_reflect(V2<R> con, R &vx, R &vy, R &d2) 
     if ((pry < (R)0 && con.y > (R)0) || (pry > (R)0 && con.y < (R)0)) vy = -pry * (R).8 * (R).8;
 }
 // bounce_ball_off_bot (RR_TrashyPhysics.py:155-245)
-template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, int r, int b, uint32_t bots_moved, int &st) {
+template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, const SimParams<typename C::Real> &sp, int r, int b, uint32_t bots_moved, int &st) {
     using R = typename C::Real;
     R vx = A.p.bvx[b], vy = A.p.bvy[b];
     if (vx == (R)0 && vy == (R)0) return;
@@ -624,8 +662,8 @@ template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, int r, int b, ui
     V2<R> bc = { A.p.bcx[b], A.p.bcy[b] };
     Seg<R> dia[2];
     force_diameters(A, r, bc, dia);
-    R px, py; const R *prel;
-    robot_prev_frame(A, r, bots_moved, px, py, prel);
+    R px, py, prel[8];
+    robot_prev_frame(A, sp, r, bots_moved, px, py, prel);
     R mvx = 0, mvy = 0;
     bool done = false;
     #pragma unroll 1
@@ -763,7 +801,7 @@ template <class C> RR_HD void ball_undo_lane(Arena<C> &A, int b) {
 }
 
 // ------------------------------------------------------------------------------------------------ sub-step pieces (RR_EnvBase.py:303-454)
-template <class C> RR_HDN void resolve_bot_collisions(Arena<C> &A, uint32_t &bots_moved, uint32_t &naughty, int &st) {
+template <class C> RR_HDN void resolve_bot_collisions(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &bots_moved, uint32_t &naughty, int &st) {
     if (C::NPR == 0) return;
     uint32_t pairs = detect_robot_pairs(A);
     int attempts = 0;
@@ -782,7 +820,7 @@ template <class C> RR_HDN void resolve_bot_collisions(Arena<C> &A, uint32_t &bot
             if (!undo) { st |= ST_BOT_STUCK; return; }
             bots_moved &= ~undo;
             RR_FOR_LANES(l) {
-                if (l < C::NR && (undo & (1u << l))) robot_undo_lane(A, l);
+                if (l < C::NR && (undo & (1u << l))) robot_undo_lane(A, sp, l);
             }
             RR_SYNC();
         }
@@ -817,7 +855,7 @@ template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimPar
         for (int p = 0; p < C::NB * C::NR; p++) {
             if (!(br & (1u << p))) continue;
             naughty = true;
-            bounce_ball_off_bot(A, p % C::NR, p / C::NR, bots_moved, st);
+            bounce_ball_off_bot(A, sp, p % C::NR, p / C::NR, bots_moved, st);
         }
         uint32_t bw = detect_ball_wall(A, sp);
         if (bw) {
@@ -865,7 +903,7 @@ RR_HDN void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real>
         balls_moved &= ~uballs;
         if (ubots | uballs) {
             RR_FOR_LANES(l) {
-                if (l < C::NR && (ubots & (1u << l))) robot_undo_lane(A, l);
+                if (l < C::NR && (ubots & (1u << l))) robot_undo_lane(A, sp, l);
                 if (l < C::NB && (uballs & (1u << l))) ball_undo_lane(A, l);
             }
             RR_SYNC();
@@ -882,7 +920,6 @@ template <class C> RR_HD void substep(Arena<C> &A, const SimParams<typename C::R
     RR_FOR_LANES(l) { // on_frame_begin (RR_Robot.py:119-120, RR_Ball.py:63-68)
         if (l < C::NR) {
             A.ax[l] = A.p.rcx[l]; A.ay[l] = A.p.rcy[l]; A.arot[l] = A.p.rrot[l];
-            for (int k = 0; k < 8; k++) A.arel[l][k] = A.rel[l][k];
         }
         if (l < C::NB) {
             A.bmass[l] = 1; A.bfx[l] = (R)0; A.bfy[l] = (R)0;
@@ -895,14 +932,14 @@ template <class C> RR_HD void substep(Arena<C> &A, const SimParams<typename C::R
     }
     RR_SYNC();
     refresh_sides(A);
-    resolve_bot_collisions(A, bots_moved, naughty, st);
+    resolve_bot_collisions(A, sp, bots_moved, naughty, st);
     { // _push_balls (RR_EnvBase.py:335-339): frozen hit list, ball-major order
         uint32_t br = detect_ball_robot(A, sp);
 #pragma unroll 1
         for (int p = 0; p < C::NB * C::NR; p++) {
             if (!(br & (1u << p))) continue;
-            apply_force_to_ball(A, p % C::NR, p / C::NR, bots_moved, st);
-            bounce_ball_off_bot(A, p % C::NR, p / C::NR, bots_moved, st);
+            apply_force_to_ball(A, sp, p % C::NR, p / C::NR, bots_moved, st);
+            bounce_ball_off_bot(A, sp, p % C::NR, p / C::NR, bots_moved, st);
         }
     }
     RR_FOR_LANES(l) { // _roll_balls
@@ -913,7 +950,6 @@ template <class C> RR_HD void substep(Arena<C> &A, const SimParams<typename C::R
     RR_FOR_LANES(l) { // the ring entry moveCount-1 of a robot whose move survived is this frame's entry
         if (l < C::NR && (bots_moved & (1u << l))) {
             A.p.px[l] = A.ax[l]; A.p.py[l] = A.ay[l]; A.p.prot[l] = A.arot[l];
-            for (int k = 0; k < 8; k++) A.prel[l][k] = A.arel[l][k];
         }
     }
     RR_SYNC();
@@ -930,44 +966,63 @@ RR_HDN bool observe(Arena<C> &A, const SimParams<typename C::Real> &sp, int team
         ridx = (team == 1) ? 0 : C::NRH;
     }
     if (bidx < 0) bidx = 0;
-    constexpr int NT = 3 * 4 * C::NR;
-    RR_FOR_LANES(l) {
-        if (l < NT) {
-            int k = l / (4 * C::NR), q = l % (4 * C::NR), j = q >> 2, s = q & 3, lst = 0;
-            V2<R> a, b; // ray start, end
-            if (k == 0) { // back-mid -> front-mid ; front = RIGHT side, back = LEFT side
-                Seg<R> fr = robot_side(A, ridx, 0), bk = robot_side(A, ridx, 2);
-                b = { (fr.a.x + fr.b.x) / (R)2, (fr.a.y + fr.b.y) / (R)2 };
-                a = { (bk.a.x + bk.b.x) / (R)2, (bk.a.y + bk.b.y) / (R)2 };
-            } else if (k == 1) { a = robot_corner(A, ridx, BL); b = robot_corner(A, ridx, TR); }
-            else { a = robot_corner(A, ridx, TL); b = robot_corner(A, ridx, BR); }
-            Seg<R> side;
-            if (j < C::NR - 1) {
-                side = robot_side(A, j < ridx ? j : j + 1, s);
-            } else { // rect_walls = FloatRect(0, W, 0, H) (RR_EnvBase.py:74)
-                R hx = sp.W / (R)2, hy = sp.H / (R)2;
-                const R wx[4] = { hx + -hx, hx + hx, hx + -hx, hx + hx }, wy[4] = { hy + -hy, hy + -hy, hy + hy, hy + hy };
-                side = { { wx[side_a(s)], wy[side_a(s)] }, { wx[side_b(s)], wy[side_b(s)] } };
+    RR_FOR_LANES(l) { if (l < C::NR) A.irot[l] = (R)NAN; } // the candidates below overwrite the aliased inner-square offsets
+    RR_SYNC();
+    // one lane per (ray, rect): minimum over the rect's four sides in registers, then over the rects below
+    constexpr int NT = 3 * C::NR;
+    for (int base = 0; base < NT; base += C::VW) {
+        RR_FOR_LANES(l) {
+            const int t = base + l;
+            if (t < NT) {
+                const int k = t / C::NR, j = t % C::NR;
+                int lst = 0;
+                V2<R> a, b; // ray start, end
+                if (k == 0) { // back-mid -> front-mid ; front = RIGHT side, back = LEFT side
+                    Seg<R> fr = robot_side(A, ridx, 0), bk = robot_side(A, ridx, 2);
+                    b = { (fr.a.x + fr.b.x) / (R)2, (fr.a.y + fr.b.y) / (R)2 };
+                    a = { (bk.a.x + bk.b.x) / (R)2, (bk.a.y + bk.b.y) / (R)2 };
+                } else if (k == 1) { a = robot_corner(A, ridx, BL); b = robot_corner(A, ridx, TR); }
+                else { a = robot_corner(A, ridx, TL); b = robot_corner(A, ridx, BR); }
+                R mr, cr;
+                slope_yint<R>(a, b, mr, cr, lst);
+                R bf = inf_<R>(), bb = inf_<R>();
+                const R hx = sp.W / (R)2, hy = sp.H / (R)2;
+#pragma unroll 1
+                for (int s = 0; s < 4; s++) {
+                    Seg<R> side;
+                    if (j < C::NR - 1) {
+                        side = robot_side(A, j < ridx ? j : j + 1, s);
+                    } else { // rect_walls = FloatRect(0, W, 0, H) (RR_EnvBase.py:74): corner = centre + (+-W/2, +-H/2)
+                        const int ca = side_a(s), cb = side_b(s);
+                        side = { { hx + ((ca & 1) ? hx : -hx), hy + ((ca & 2) ? hy : -hy) },
+                                 { hx + ((cb & 1) ? hx : -hx), hy + ((cb & 2) ? hy : -hy) } };
+                    }
+                    R ms, cs;
+                    slope_yint<R>(side.a, side.b, ms, cs, lst);
+                    V2<R> I = intersect_mb<R>(ms, cs, side.a.x, mr, cr, a.x);
+                    R de = dist<R>(I, b), ds = dist<R>(I, a);
+                    if (de <= ds && de < bf) bf = de;
+                    if (ds <= de && ds < bb) bb = ds;
+                }
+                A.u.lidar[0][t] = bf;
+                A.u.lidar[1][t] = bb;
             }
-            Seg<R> ray = { a, b };
-            V2<R> I = line_intersection<R>(side, ray, lst);
-            R de = dist<R>(I, b), ds = dist<R>(I, a);
-            A.lf[l] = (de <= ds) ? de : inf_<R>();
-            A.lb[l] = (ds <= de) ? ds : inf_<R>();
         }
     }
     RR_SYNC();
-    RR_FOR_LANES(l) { // min over (rect, side) in list order: one lane per (ray, direction)
-        if (l < 6) {
-            const R *src = (l & 1) ? A.lb : A.lf;
-            const int k = l >> 1;
-            R best = inf_<R>();
-#pragma unroll 1
-            for (int q = 0; q < 4 * C::NR; q++) {
-                R v = src[k * 4 * C::NR + q];
-                if (v < best) best = v;
+    for (int base = 0; base < 6; base += C::VW) {
+        RR_FOR_LANES(l) { // min over the rects: one lane per (ray, direction)
+            const int t = base + l;
+            if (t < 6) {
+                const R *src = (t & 1) ? A.u.lidar[1] : A.u.lidar[0];
+                const int k = t >> 1;
+                R best = inf_<R>();
+                for (int q = 0; q < C::NR; q++) {
+                    R v = src[k * C::NR + q];
+                    if (v < best) best = v;
+                }
+                A.lid[t] = py_min<R>(best, (R)150);
             }
-            A.lid[l] = py_min<R>(best, (R)150);
         }
     }
     RR_SYNC();
@@ -1004,8 +1059,6 @@ template <class C> RR_HD void derive(Arena<C> &A, const SimParams<typename C::Re
     RR_FOR_LANES(l) {
         if (l < C::NR) {
             corners_for<R>(A.p.rrot[l], (R)10, (R)20, sp.rob_cdist, A.rel[l]);
-            if (!is_nan(A.p.px[l]))
-                corners_for<R>(py_mod<R>(A.p.prot[l] + (R)720, (R)360), (R)10, (R)20, sp.rob_cdist, A.prel[l]);
             A.irot[l] = (R)NAN; // inner-square offsets are built lazily by the first narrow phase that needs them
         }
     }
@@ -1141,7 +1194,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
             observe<C, O>(A, sp, 1, -1, -1, o.obs, st);
             if (o.obs_g) {
                 if (!observe<C, O>(A, sp, -1, -1, -1, o.obs_g, st)) {
-                    RR_FOR_LANES(l) { if (l < 11) o.obs_g[l] = (O)NAN; }
+                    for (int base = 0; base < 11; base += C::VW) { RR_FOR_LANES(l) { if (base + l < 11) o.obs_g[base + l] = (O)NAN; } }
                 }
             }
             if (RR_IS_LANE0) {
@@ -1155,7 +1208,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
         observe<C, O>(A, sp, 1, -1, -1, o.obs, st);
         if (o.obs_g) {
             if (!observe<C, O>(A, sp, -1, -1, -1, o.obs_g, st)) {
-                RR_FOR_LANES(l) { if (l < 11) o.obs_g[l] = (O)NAN; }
+                for (int base = 0; base < 11; base += C::VW) { RR_FOR_LANES(l) { if (base + l < 11) o.obs_g[base + l] = (O)NAN; } }
             }
         }
         if (RR_IS_LANE0) {
@@ -1221,7 +1274,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     observe<C, O>(A, sp, 1, -1, -1, o.obs, st);
     if (o.obs_g) {
         if (!observe<C, O>(A, sp, -1, -1, -1, o.obs_g, st)) {
-            RR_FOR_LANES(l) { if (l < 11) o.obs_g[l] = (O)NAN; }
+            for (int base = 0; base < 11; base += C::VW) { RR_FOR_LANES(l) { if (base + l < 11) o.obs_g[base + l] = (O)NAN; } }
         }
     }
     if (RR_IS_LANE0) {

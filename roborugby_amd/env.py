@@ -238,6 +238,11 @@ class BatchedRoboRugbyEnv:
                    "rr_episode_stats")
         return lr, lrg, ll, cnt
 
+    def lanes_per_env(self):
+        v = C.c_int32()
+        _lib.check(self._lib.rr_lanes_per_env(self._h, C.byref(v)), "rr_lanes_per_env")
+        return v.value
+
     def state_bytes_per_env(self):
         b = C.c_int64()
         _lib.check(self._lib.rr_state_bytes_per_env(self._h, C.byref(b)), "rr_state_bytes_per_env")

@@ -60,10 +60,13 @@ template <class C> static void get_state(Emu<C> *e, double *robots, int32_t *ri,
     *step = A.i.step;
 }
 
-typedef Cfg<1, 0, 1, 0, double> CT64;
-typedef Cfg<2, 2, 4, 4, double> CG64;
-typedef Cfg<1, 0, 1, 0, float> CT32;
-typedef Cfg<2, 2, 4, 4, float> CG32;
+typedef Cfg<1, 0, 1, 0, double, 64> CT64;
+typedef Cfg<2, 2, 4, 4, double, 64> CG64;
+typedef Cfg<1, 0, 1, 0, float, 64> CT32;
+typedef Cfg<2, 2, 4, 4, float, 64> CG32;
+// narrow virtual waves: the same phases run in several rounds of VW lanes (what the packed GPU builds execute)
+typedef Cfg<1, 0, 1, 0, double, 4> CT64n;
+typedef Cfg<2, 2, 4, 4, double, 16> CG64n;
 
 struct Handle { int kind; void *p; };
 
@@ -73,10 +76,12 @@ struct Handle { int kind; void *p; };
     case 1: { auto *e = (Emu<CG64> *)(h)->p; typedef CG64 CC; __VA_ARGS__; } break; \
     case 2: { auto *e = (Emu<CT32> *)(h)->p; typedef CT32 CC; __VA_ARGS__; } break; \
     case 3: { auto *e = (Emu<CG32> *)(h)->p; typedef CG32 CC; __VA_ARGS__; } break; \
+    case 4: { auto *e = (Emu<CT64n> *)(h)->p; typedef CT64n CC; __VA_ARGS__; } break; \
+    case 5: { auto *e = (Emu<CG64n> *)(h)->p; typedef CG64n CC; __VA_ARGS__; } break; \
     }
 
 extern "C" {
-// preset: 0 = T, 1 = G ; f32: 0/1
+// preset: 0 = T, 1 = G ; f32: 0/1 ; f32 == 2 selects the narrow-virtual-wave fp64 build
 Handle *emu_create(int preset, int f32, double W, double H, int game_len, int game_mode, int time_limit, int auto_reset,
                    uint64_t seed) {
     Handle *h = new Handle;
@@ -85,7 +90,9 @@ Handle *emu_create(int preset, int f32, double W, double H, int game_len, int ga
     case 0: h->p = calloc(1, sizeof(Emu<CT64>)); break;
     case 1: h->p = calloc(1, sizeof(Emu<CG64>)); break;
     case 2: h->p = calloc(1, sizeof(Emu<CT32>)); break;
-    default: h->p = calloc(1, sizeof(Emu<CG32>)); break;
+    case 3: h->p = calloc(1, sizeof(Emu<CG32>)); break;
+    case 4: h->p = calloc(1, sizeof(Emu<CT64n>)); break;
+    default: h->p = calloc(1, sizeof(Emu<CG64n>)); break;
     }
     DISPATCH(h, fill_params(e->sp, W, H, game_len, game_mode, time_limit, auto_reset, seed); (void)sizeof(CC);
              for (int r = 0; r < CC::NR; r++) robot_set_clean_lane(e->A, e->sp, r, (typename CC::Real)0, (typename CC::Real)0,

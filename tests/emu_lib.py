@@ -52,12 +52,13 @@ def _ip(a):
 
 
 class EmuEnv:
-    def __init__(self, preset="T", f32=False, time_limit=0, auto_reset=0, seed=0):
+    def __init__(self, preset="T", f32=False, time_limit=0, auto_reset=0, seed=0, narrow=False):
         cfg = ol.PRESETS[preset]
         self.cfg = cfg
         self.nr = cfg["nr_h"] + cfg["nr_g"]
         self.nb = cfg["nb_p"] + cfg["nb_n"]
-        self.h = lib().emu_create(0 if preset == "T" else 1, int(f32), cfg["W"], cfg["H"], cfg["game_len"],
+        # narrow=True: fp64 with VW = 4 (T) / 16 (G) lanes per arena, i.e. multi-round phases as in the packed builds
+        self.h = lib().emu_create(0 if preset == "T" else 1, 2 if narrow else int(f32), cfg["W"], cfg["H"], cfg["game_len"],
                                   cfg["game_mode"], time_limit, auto_reset, seed)
 
     def __del__(self):

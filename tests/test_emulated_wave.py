@@ -16,10 +16,12 @@ def _diff(st, ref_r, ref_b):
     return max(float(np.nanmax(np.abs(st["robots"] - ref_r))), float(np.abs(st["balls"] - ref_b).max()))
 
 
-@pytest.mark.parametrize("preset,stride", [("T", 3), ("G", 4)])
-def test_emulated_kernel_vs_reference_golden(golden_dir, preset, stride):
+@pytest.mark.parametrize("preset,stride,narrow", [("T", 3, False), ("G", 4, False), ("T", 4, True), ("G", 5, True)])
+def test_emulated_kernel_vs_reference_golden(golden_dir, preset, stride, narrow):
+    """narrow=True runs the phases with VW = 4 (T) / 16 (G) lanes per arena, i.e. in several rounds -- the
+    lane->task maps of the packed GPU builds (several arenas per wavefront)."""
     t = np.load(f"{golden_dir}/traj_{preset}.npz")
-    env = el.EmuEnv(preset)
+    env = el.EmuEnv(preset, narrow=narrow)
     worst, n = 0.0, 0
     for ep in range(t["length"].shape[0]):
         for s in range(ep % stride, int(t["length"][ep]), stride):
