@@ -26,8 +26,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--arenas", type=int, default=65536, help="arenas per GPU (weak scaling)")
     ap.add_argument("--preset", default="G", choices=["G", "T"],
                     help="G = constants as checked in (2+2 robots, 4+4 balls, 800x800); T = DQN training preset")

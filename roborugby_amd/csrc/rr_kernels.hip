@@ -204,10 +204,10 @@ __global__ void k_episode_stats(const typename C::Real *recs, const int32_t *ire
 // Built configurations: (kind = shape + 2*dtype, entity counts, Real, VW).  The first VW listed for a kind is the
 // default; the environment variable RR_VW selects another built width (kernel tuning / A-B runs).
 #define RR_FOR_EACH_CFG(X)                                                                             \
-    X(0, 1, 0, 1, 0, double, 4) X(0, 1, 0, 1, 0, double, 8) X(0, 1, 0, 1, 0, double, 16) X(0, 1, 0, 1, 0, double, 64) \
-    X(1, 2, 2, 4, 4, double, 16) X(1, 2, 2, 4, 4, double, 32) X(1, 2, 2, 4, 4, double, 64)               \
-    X(2, 1, 0, 1, 0, float, 4) X(2, 1, 0, 1, 0, float, 8) X(2, 1, 0, 1, 0, float, 16) X(2, 1, 0, 1, 0, float, 64)     \
-    X(3, 2, 2, 4, 4, float, 16) X(3, 2, 2, 4, 4, float, 32) X(3, 2, 2, 4, 4, float, 64)
+    X(0, 1, 0, 1, 0, double, 2) X(0, 1, 0, 1, 0, double, 4) X(0, 1, 0, 1, 0, double, 8) X(0, 1, 0, 1, 0, double, 64) \
+    X(1, 2, 2, 4, 4, double, 8) X(1, 2, 2, 4, 4, double, 16) X(1, 2, 2, 4, 4, double, 32) X(1, 2, 2, 4, 4, double, 64) \
+    X(2, 1, 0, 1, 0, float, 2) X(2, 1, 0, 1, 0, float, 4) X(2, 1, 0, 1, 0, float, 64)                                 \
+    X(3, 2, 2, 4, 4, float, 8) X(3, 2, 2, 4, 4, float, 16) X(3, 2, 2, 4, 4, float, 64)
 
 struct rr_env {
     rr_config cfg;

@@ -215,7 +215,6 @@ template <int NRH_, int NRG_, int NBP_, int NBN_, typename Real_, int VW_ = 64> 
     using Real = Real_;
     static_assert(VW == 2 || VW == 4 || VW == 8 || VW == 16 || VW == 32 || VW == 64, "VW must divide the wavefront");
     static_assert(NR >= 1 && NR <= VW && NB >= 1 && NB <= VW, "one lane per entity");
-    static_assert(NPR == 0 || VW >= 16, "robot-pair tasks come in groups of 16 (side x side)");
     static_assert(NB * NR <= 32 && NPB <= 64, "pair masks are 32/64-bit");
 };
 
@@ -457,28 +456,49 @@ template <class C> RR_HD void pair_of(int p, int n, int &i, int &j) { // p-th (i
 }
 template <class C> RR_HD uint32_t detect_robot_pairs(const Arena<C> &A) {
     using R = typename C::Real;
-    uint32_t pairs = 0;
-    constexpr int NT = C::NPR * 16;
-    for (int base = 0; base < NT; base += C::VW) {
+    if (C::NPR == 0) return 0;
+    // broad phase: one lane per pair
+    uint32_t close = 0;
+    for (int base = 0; base < C::NPR; base += C::VW) {
         uint64_t m = 0;
         RR_FOR_LANES(l) {
-            bool hit = false;
+            bool c = false;
             int t = base + l;
-            if (t < NT) {
+            if (t < C::NPR) {
                 int i, j;
-                pair_of<C>(t >> 4, C::NR, i, j);
+                pair_of<C>(t, C::NR, i, j);
                 R dx = A.p.rcx[j] - A.p.rcx[i], dy = A.p.rcy[j] - A.p.rcy[i];
-                if (dx * dx + dy * dy <= cull_rr2<R>()) {
-                    int s1 = (t >> 2) & 3, s2 = t & 3;
-                    Seg<R> g1 = robot_side(A, i, s1), g2 = robot_side(A, j, s2);
-                    V2<R> p = intersect_mb<R>(A.sm[i][s1], A.sc[i][s1], g1.a.x, A.sm[j][s2], A.sc[j][s2], g2.a.x);
-                    hit = within<R>(p, g1, (R)0) & within<R>(p, g2, (R)0);
-                }
+                c = dx * dx + dy * dy <= cull_rr2<R>();
             }
-            RR_VOTE(m, l, hit);
+            RR_VOTE(m, l, c);
         }
-        for (int q = 0; q < C::VW / 16; q++)
-            if ((m >> (16 * q)) & 0xFFFFull) pairs |= 1u << ((base >> 4) + q);
+        close |= (uint32_t)(m << base);
+    }
+    if (!close) return 0;
+    // narrow phase: the 16 (side, side) tests of each close pair, VW of them per round
+    uint32_t pairs = 0;
+#pragma unroll 1
+    for (int p = 0; p < C::NPR; p++) {
+        if (!(close & (1u << p))) continue;
+        int i, j;
+        pair_of<C>(p, C::NR, i, j);
+        uint64_t any = 0;
+        for (int base = 0; base < 16; base += C::VW) {
+            uint64_t m = 0;
+            RR_FOR_LANES(l) {
+                bool hit = false;
+                int t = base + l;
+                if (t < 16) {
+                    int s1 = t >> 2, s2 = t & 3;
+                    Seg<R> g1 = robot_side(A, i, s1), g2 = robot_side(A, j, s2);
+                    V2<R> q = intersect_mb<R>(A.sm[i][s1], A.sc[i][s1], g1.a.x, A.sm[j][s2], A.sc[j][s2], g2.a.x);
+                    hit = within<R>(q, g1, (R)0) & within<R>(q, g2, (R)0);
+                }
+                RR_VOTE(m, l, hit);
+            }
+            any |= m;
+        }
+        if (any) pairs |= 1u << p;
     }
     return pairs;
 }
@@ -486,39 +506,39 @@ template <class C> RR_HD uint32_t detect_robot_pairs(const Arena<C> &A) {
 // corners against the radius and its diameter against the four sides.  Bit (b*NR + r) of the result.
 template <class C> RR_HD uint32_t detect_ball_robot(Arena<C> &A, const SimParams<typename C::Real> &sp) {
     using R = typename C::Real;
-    constexpr int NT = C::NB * C::NR * 2;
-    constexpr int NROUND = (NT + C::VW - 1) / C::VW;
-    uint64_t close[NROUND];
-    bool any = false;
-    for (int k = 0; k < NROUND; k++) {
+    constexpr int NP = C::NB * C::NR;
+    // broad phase: one lane per (ball, robot) pair
+    uint32_t close = 0;
+    for (int base = 0; base < NP; base += C::VW) {
         uint64_t cm = 0;
         RR_FOR_LANES(l) {
             bool c = false;
-            int t = k * C::VW + l;
-            if (t < NT) {
-                int pr = t >> 1, r = pr % C::NR, b = pr / C::NR;
+            int t = base + l;
+            if (t < NP) {
+                int r = t % C::NR, b = t / C::NR;
                 R dx = A.p.bcx[b] - A.p.rcx[r], dy = A.p.bcy[b] - A.p.rcy[r];
                 c = dx * dx + dy * dy <= cull_br2<R>();
             }
             RR_VOTE(cm, l, c);
         }
-        close[k] = cm;
-        any = any | (cm != 0);
+        close |= (uint32_t)(cm << base);
     }
-    if (!any) return 0;
+    if (!close) return 0;
     // narrow phase: the inner-square corner offsets (rot+45) are only needed now
     RR_FOR_LANES(l) {
         if (l < C::NR) refresh_inner_lane(A, sp, l);
     }
     RR_SYNC();
     uint32_t pairs = 0;
-    for (int k = 0; k < NROUND; k++) {
-        if (!close[k]) continue;
+    constexpr int NT = NP * 2; // task = (pair, diameter)
+    for (int base = 0; base < NT; base += C::VW) {
+        constexpr uint32_t ALL = (C::VW >= 64) ? 0xFFFFFFFFu : ((1u << (C::VW / 2)) - 1u);
+        if (!((close >> (base >> 1)) & ALL)) continue;
         uint64_t m = 0;
         RR_FOR_LANES(l) {
             bool hit = false;
-            if ((close[k] >> l) & 1) {
-                int t = k * C::VW + l;
+            int t = base + l;
+            if (t < NT && ((close >> (t >> 1)) & 1u)) {
                 int d = t & 1, pr = t >> 1, r = pr % C::NR, b = pr / C::NR, st = 0;
                 V2<R> bc = { A.p.bcx[b], A.p.bcy[b] };
                 hit = (dist<R>(robot_corner(A, r, 2 * d), bc) < (R)7) | (dist<R>(robot_corner(A, r, 2 * d + 1), bc) < (R)7);
@@ -530,14 +550,14 @@ template <class C> RR_HD uint32_t detect_ball_robot(Arena<C> &A, const SimParams
                 slope_yint<R>(dia.a, dia.b, md, cd, st);
                 for (int sd = 0; sd < 4; sd++) {
                     Seg<R> side = robot_side(A, r, sd);
-                    V2<R> p = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, md, cd, dia.a.x);
-                    hit = hit | (within<R>(p, side, (R)0) & within<R>(p, dia, (R)0));
+                    V2<R> q = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, md, cd, dia.a.x);
+                    hit = hit | (within<R>(q, side, (R)0) & within<R>(q, dia, (R)0));
                 }
             }
             RR_VOTE(m, l, hit);
         }
         for (int q = 0; q < C::VW / 2; q++)
-            if ((m >> (2 * q)) & 3ull) pairs |= 1u << (k * (C::VW / 2) + q);
+            if ((m >> (2 * q)) & 3ull) pairs |= 1u << ((base >> 1) + q);
     }
     return pairs;
 }
@@ -555,7 +575,9 @@ template <class C> RR_HD uint64_t detect_ball_pairs(const Arena<C> &A) {
                 int i, j;
                 pair_of<C>(t, C::NB, i, j);
                 V2<R> a = { A.p.bcx[i], A.p.bcy[i] }, b = { A.p.bcx[j], A.p.bcy[j] };
-                hit = dist<R>(a, b) <= (R)14;
+                R dx = b.x - a.x, dy = b.y - a.y;
+                // sqrt(x) <= 14 needs x <= 196 (+ulps): only then is the reference's own test evaluated
+                if (dx * dx + dy * dy <= (R)197) hit = dist<R>(a, b) <= (R)14;
             }
             RR_VOTE(m, l, hit);
         }

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Condenses a tools/profile_r01.sh run (gpurun_out/prof_<tag>/) into profiles/<round>/ + profiles/traffic.json.
+usage: tools/summarize_profile.py <tag> <key e.g. G_f64_65536> <round dir e.g. r01>"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag, key, rnd = sys.argv[1], sys.argv[2], sys.argv[3]
+base = f"gpurun_out/prof_{tag}"
+out_dir = f"profiles/{rnd}"
+os.makedirs(out_dir, exist_ok=True)
+ks = glob.glob(f"{base}/stats/*/*_kernel_stats.csv")[0]
+shutil.copy(ks, f"{out_dir}/{key}_kernel_stats.csv")
+step_row = [r for r in csv.DictReader(open(ks)) if "k_step" in r["Name"]][0]
+out = {"kernel": step_row["Name"][:60] + "...", "calls": int(step_row["Calls"]), "avg_ns": float(step_row["AverageNs"]),
+       "min_ns": float(step_row["MinNs"]), "max_ns": float(step_row["MaxNs"]), "pct_of_gpu_time": float(step_row["Percentage"])}
+n_env = int(key.split("_")[-1])
+for kind in ("fetch", "write"):
+    f = glob.glob(f"{base}/pmc_{kind}/*/*_counter_collection.csv")[0]
+    rows = [r for r in csv.DictReader(open(f)) if "k_step" in r["Kernel_Name"]]
+    vals = [float(r["Counter_Value"]) for r in rows]
+    out[rows[0]["Counter_Name"]] = dict(per_launch_values_KB=vals, mean_KB=sum(vals) / len(vals))
+    out["kernel_resources"] = dict(VGPR=int(rows[0]["VGPR_Count"]), AGPR=int(rows[0]["Accum_VGPR_Count"]),
+                                   SGPR=int(rows[0]["SGPR_Count"]), LDS_block=int(rows[0]["LDS_Block_Size"]),
+                                   scratch=int(rows[0]["Scratch_Size"]), workgroup=int(rows[0]["Workgroup_Size"]),
+                                   grid=int(rows[0]["Grid_Size"]))
+f_, w_ = out["FETCH_SIZE"]["mean_KB"] * 1024, out["WRITE_SIZE"]["mean_KB"] * 1024
+out["hbm_bytes_per_launch"] = dict(
+    fetch_raw=f_, fetch_corrected_x2=2 * f_, write=w_, total=2 * f_ + w_,
+    note="gfx950: FETCH_SIZE tallies 128-B read requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM section); "
+         "FETCH_SIZE and WRITE_SIZE come from separate --pmc passes; record loads are contiguous lane-strided runs")
+out["hbm_bytes_per_env_step"] = (2 * f_ + w_) / n_env
+json.dump(out, open(f"{out_dir}/{key}_summary.json", "w"), indent=1)
+tf = "profiles/traffic.json"
+t = json.load(open(tf)) if os.path.exists(tf) else {}
+t[key] = 2 * f_ + w_
+json.dump(t, open(tf, "w"), indent=1)
+print(json.dumps({k: out[k] for k in ("avg_ns", "hbm_bytes_per_env_step", "kernel_resources")}))
