@@ -99,6 +99,8 @@ def main():
     from roborugby_amd import dist as rrd
 
     rank, local_rank, world = rrd.init_process_group()
+    if os.environ.get("RR_BENCH_SHARE_GPU"):  # rehearsal of the N>1 path on a 1-GPU box: every rank uses cuda:0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     n = args.arenas

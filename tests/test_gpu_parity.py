@@ -94,3 +94,35 @@ def test_reset_matches_oracle_bit_exact(preset):
         assert np.array_equal(ost["balls"], st["balls"][a]), a
         assert np.allclose(o.observe(1), obs[a], rtol=0, atol=1e-3)
     assert (st["step"] == 0).all()
+
+
+@pytest.mark.parametrize("preset", ["T", "G"])
+def test_free_running_episodes_vs_reference(golden_dir, preset):
+    """Whole golden episodes replayed WITHOUT re-synchronisation (each episode = one arena started from the
+    reference's step-0 state, driven by the recorded actions).  The dynamics are chaotic once contact responses
+    fire: a 1-ulp libm/ocml difference is amplified by every bounce, so contact-rich episodes leave the reference
+    trajectory after some tens of steps while contact-free ones stay within 1e-12 for all 301 steps
+    (hard part 2 -- long-run parity is statistical).  Asserted here: every episode tracks
+    the reference to 1e-9 for at least its first 20 steps, done flags are exact throughout, and a substantial share
+    of the episodes tracks to the very end."""
+    t = np.load(f"{golden_dir}/traj_{preset}.npz")
+    na_used = (t["actions"][:, 0, :] >= 0).sum(1)
+    full = np.nonzero(na_used == na_used.max())[0]  # episodes that drive every robot (one launch shape)
+    env = _env(preset, len(full))
+    env.set_state(t["state_robots"][full, 0], t["state_robots_i"][full, 0], t["state_balls"][full, 0], t["state_step"][full, 0])
+    L = t["length"][full]
+    first_bad = np.full(len(full), 10 ** 6)
+    for s in range(int(L.max())):
+        acts = np.clip(t["actions"][full, s, :na_used.max()], 0, 7).astype(np.int32)
+        o, r, d, info = env.step_f64(torch.as_tensor(acts))
+        o, d = o.cpu().numpy(), d.cpu().numpy()
+        for i, ep in enumerate(full):
+            if s < L[i]:
+                assert bool(d[i]) == bool(t["done"][ep, s])
+                if np.abs(o[i] - t["obs"][ep, s]).max() > 1e-9 and first_bad[i] > s:
+                    first_bad[i] = s
+    tracked = int((first_bad >= L).sum())
+    print(f"[{preset}] {len(full)} free-running episodes: {tracked} track the reference to 1e-9 until their end; "
+          f"first departure of the others at steps {sorted(int(x) for x in first_bad[first_bad < L])}")
+    assert (np.minimum(first_bad, L) >= np.minimum(20, L)).all()
+    assert tracked >= (6 if preset == "T" else 2)
