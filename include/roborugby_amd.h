@@ -59,6 +59,9 @@ typedef struct rr_config {
                                Training_DQN_pytorch.py); 0: done = step_count > T (raw RR_EnvBase.py:555-559) */
     int32_t auto_reset;     /* 1: rr_step on a finished arena resets it (status WAS_RESET, reward 0, done 0)
                                instead of flagging STEP_AFTER_DONE                                     */
+    int32_t reset_on_fault; /* 1: a step that ends with a fatal status (the places where the reference raises or
+                               spins forever: bits 1|2|4|8|16|32) reports done = 1 and ends the episode, so that
+                               auto_reset re-places the arena; 0: the arena keeps stepping with the bit set     */
     int32_t dtype;          /* RR_DTYPE_F64 | RR_DTYPE_F32                                             */
     int32_t device;         /* HIP device ordinal                                                      */
     uint64_t seed;          /* keys the counter-based reset RNG                                        */

@@ -20,6 +20,7 @@ class RRConfig(C.Structure):
         ("nr_happy", C.c_int32), ("nr_grumpy", C.c_int32), ("nb_pos", C.c_int32), ("nb_neg", C.c_int32),
         ("arena_w", C.c_double), ("arena_h", C.c_double),
         ("game_len_steps", C.c_int32), ("game_mode", C.c_int32), ("time_limit", C.c_int32), ("auto_reset", C.c_int32),
+        ("reset_on_fault", C.c_int32),
         ("dtype", C.c_int32), ("device", C.c_int32),
         ("seed", C.c_uint64), ("arena_offset", C.c_uint64),
     ]

@@ -145,6 +145,7 @@ __global__ void k_set_state(typename C::Real *recs, int32_t *irecs, int n, const
     for (int b = 0; b < NB; b++)
         for (int f = 0; f < 8; f++) rec[10 * NR + f * NB + b] = (R)balls[((size_t)a * NB + b) * 8 + f];
     irec[3 * NR + 0] = step[a];
+    irec[3 * NR + 5] = 0; // fault flag
 }
 template <class C>
 __global__ void k_get_state(const typename C::Real *recs, const int32_t *irecs, int n, double *robots, int32_t *ri,
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_set_poses(SimParams<ty
         const double *q = bxyv + ((size_t)arena * C::NB + lane) * 4;
         ball_set_clean_lane(A, lane, (R)q[0], (R)q[1], (R)q[2], (R)q[3]);
     }
-    if (lane == 0) { A.i.step = 0; A.i.ep_len = 0; A.p.acc[0] = (R)0; A.p.acc[1] = (R)0; }
+    if (lane == 0) { A.i.step = 0; A.i.ep_len = 0; A.i.fault = 0; A.p.acc[0] = (R)0; A.p.acc[1] = (R)0; }
     store_record(A, rec, irec);
 }
 template <class C>
@@ -239,6 +240,7 @@ template <typename R> static void fill_params(SimParams<R> &sp, const rr_config 
     sp.inner_h = (R)hr;
     sp.inner_cdist = (R)std::pow(hr * hr + hr * hr, .5);
     sp.game_len = c.game_len_steps; sp.game_mode = c.game_mode; sp.time_limit = c.time_limit; sp.auto_reset = c.auto_reset;
+    sp.reset_on_fault = c.reset_on_fault;
     sp.seed = c.seed; sp.arena_offset = c.arena_offset;
 }
 template <typename R> static const SimParams<R> &params_of(const rr_env *e);

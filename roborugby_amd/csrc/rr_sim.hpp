@@ -223,7 +223,7 @@ template <typename R> struct SimParams {
     R mult_ball, mult_robot;     // RR_Constants.py:46,50
     R rob_cdist;                 // FloatRect._corner_dist of a 20x40 rect (MyUtils.py:138)
     R inner_h, inner_cdist;      // half side / corner dist of _rectBallInner (RR_TrashyPhysics.py:29-35)
-    int32_t game_len, game_mode, time_limit, auto_reset;
+    int32_t game_len, game_mode, time_limit, auto_reset, reset_on_fault;
     uint64_t seed, arena_offset;
 };
 
@@ -244,7 +244,7 @@ template <class C> struct Arena {
     } p;
     struct I {
         int32_t mc[NR], thl[NR], thr[NR];
-        int32_t step, episode, ep_len, ep_count, last_len;
+        int32_t step, episode, ep_len, ep_count, last_len, fault;
     } i;
     // ---- per-step scratch
     R rel[NR][8];   // corner offsets TL,TR,BL,BR (x,y) for the current rotation
@@ -254,11 +254,15 @@ template <class C> struct Arena {
     R psx[NR], psy[NR]; // robot centre at step begin (rectDblPriorStep)
     R bfx[NB], bfy[NB], pfx[NB], pfy[NB];
     int32_t bmass[NB];
+    int32_t sides_ok; // sm/sc match the current robot poses (rebuilt lazily by the first phase that needs them)
     union { // the lidar candidates are only alive inside observe(), the inner-square offsets only inside a sub-step
         R irel[NR][8];                    // corner offsets of the ball's inner square at rot+45 (diameter end points)
         R lidar[2][3 * NR];               // [front|back][ray, rect] minima over the rect's four sides
     } u;
     R lid[6];                             // capped minima: front/back per ray
+#ifdef RR_LDS_PAD
+    R pad_[NR > 1 ? RR_LDS_PAD : 1]; // occupancy experiments only
+#endif
     static constexpr int P_REALS = (int)(sizeof(P) / sizeof(R));
     static constexpr int I_INTS = (int)(sizeof(I) / sizeof(int32_t));
     static constexpr int P_STRIDE = (P_REALS + 15) / 16 * 16; // record strides in HBM (128-B multiples)
@@ -331,6 +335,7 @@ template <class C> RR_HD void store_robot(Arena<C> &A, int r, const FR<typename 
     A.p.rcx[r] = f.cx; A.p.rcy[r] = f.cy; A.p.rl[r] = f.l; A.p.rrt[r] = f.r; A.p.rt[r] = f.t; A.p.rb[r] = f.b;
     A.p.rrot[r] = f.rot;
     for (int k = 0; k < 8; k++) A.rel[r][k] = f.rel[k];
+    A.sides_ok = 0;
 }
 template <class C> RR_HD V2<typename C::Real> robot_corner(const Arena<C> &A, int r, int c) {
     V2<typename C::Real> v = { A.p.rcx[r] + A.rel[r][2 * c], A.p.rcy[r] + A.rel[r][2 * c + 1] };
@@ -422,9 +427,10 @@ template <class C> RR_HD void refresh_inner_lane(Arena<C> &A, const SimParams<ty
     corners_for<R>(py_mod<R>(rot + (R)45 + (R)720, (R)360), sp.inner_h, sp.inner_h, sp.inner_cdist, A.u.irel[r]);
 }
 
-// side slope/intercept cache: one lane per (robot, side); must follow every robot pose change
-template <class C> RR_HD void refresh_sides(Arena<C> &A) {
+// side slope/intercept cache: one lane per (robot, side), rebuilt on demand after robot poses changed
+template <class C> RR_HD void ensure_sides(Arena<C> &A) {
     using R = typename C::Real;
+    if (A.sides_ok) return; // same value in every lane of the arena (read after a sync)
     for (int base = 0; base < 4 * C::NR; base += C::VW) {
         RR_FOR_LANES(l) {
             int t = base + l;
@@ -437,6 +443,8 @@ template <class C> RR_HD void refresh_sides(Arena<C> &A) {
             }
         }
     }
+    RR_SYNC();
+    if (RR_IS_LANE0) A.sides_ok = 1;
     RR_SYNC();
 }
 // Exact broad phase.  A hit of robots_collided / ball_robot_collided needs an intersection point inside the
@@ -454,7 +462,7 @@ template <class C> RR_HD void pair_of(int p, int n, int &i, int &j) { // p-th (i
     while (p >= n - 1 - i) { p -= n - 1 - i; i++; }
     j = i + 1 + p;
 }
-template <class C> RR_HD uint32_t detect_robot_pairs(const Arena<C> &A) {
+template <class C> RR_HD uint32_t detect_robot_pairs(Arena<C> &A) {
     using R = typename C::Real;
     if (C::NPR == 0) return 0;
     // broad phase: one lane per pair
@@ -475,6 +483,7 @@ template <class C> RR_HD uint32_t detect_robot_pairs(const Arena<C> &A) {
         close |= (uint32_t)(m << base);
     }
     if (!close) return 0;
+    ensure_sides(A);
     // narrow phase: the 16 (side, side) tests of each close pair, VW of them per round
     uint32_t pairs = 0;
 #pragma unroll 1
@@ -529,6 +538,7 @@ template <class C> RR_HD uint32_t detect_ball_robot(Arena<C> &A, const SimParams
         if (l < C::NR) refresh_inner_lane(A, sp, l);
     }
     RR_SYNC();
+    ensure_sides(A);
     uint32_t pairs = 0;
     constexpr int NT = NP * 2; // task = (pair, diameter)
     for (int base = 0; base < NT; base += C::VW) {
@@ -620,6 +630,54 @@ template <class C> RR_HD void force_diameters(const Arena<C> &A, int r, V2<typen
     dia[0].a = { bc.x + q[2 * BL], bc.y + q[2 * BL + 1] }; dia[0].b = { bc.x + q[2 * TR], bc.y + q[2 * TR + 1] };
     dia[1].a = { bc.x + q[2 * BR], bc.y + q[2 * BR + 1] }; dia[1].b = { bc.x + q[2 * TL], bc.y + q[2 * TL + 1] };
 }
+// First (side, diameter) candidate -- sides in RIGHT,TOP,LEFT,BOTTOM order, diameters (BL->TR) then (BR->TL) -- whose
+// intersection lies within the side and within the diameter grown by `buf`: the surface-contact search shared by
+// apply_force_to_ball / bounce_ball_off_bot (RR_TrashyPhysics.py:110-115, :180-186).  The eight candidates are
+// independent, so they are tested one per lane and the ballot's lowest set bit is the reference's first hit.
+template <class C>
+RR_HD int first_surface_hit(Arena<C> &A, int r, const Seg<typename C::Real> dia[2], typename C::Real buf) {
+    using R = typename C::Real;
+    uint32_t hits = 0;
+    for (int base = 0; base < 8; base += C::VW) {
+        uint64_t m = 0;
+        RR_FOR_LANES(l) {
+            bool hit = false;
+            const int t = base + l;
+            if (t < 8) {
+                const int sd = t >> 1, d = t & 1;
+                int st = 0;
+                Seg<R> side = robot_side(A, r, sd);
+                V2<R> I = line_intersection<R>(side, dia[d], st);
+                hit = within<R>(I, side, (R)0) & within<R>(I, dia[d], buf);
+            }
+            RR_VOTE(m, l, hit);
+        }
+        hits |= (uint32_t)(m << base);
+    }
+    if (!hits) return -1;
+    int k = 0;
+    while (!((hits >> k) & 1u)) k++;
+    return k;
+}
+// same idea for the corner-contact search: first corner (TL,TR,BL,BR) closer to the ball centre than `rad`
+template <class C>
+RR_HD int first_corner_hit(Arena<C> &A, int r, V2<typename C::Real> bc, typename C::Real rad) {
+    using R = typename C::Real;
+    uint32_t hits = 0;
+    for (int base = 0; base < 4; base += C::VW) {
+        uint64_t m = 0;
+        RR_FOR_LANES(l) {
+            const int t = base + l;
+            bool hit = (t < 4) && (dist<R>(robot_corner(A, r, t < 4 ? t : 0), bc) < rad);
+            RR_VOTE(m, l, hit);
+        }
+        hits |= (uint32_t)(m << base);
+    }
+    if (!hits) return -1;
+    int k = 0;
+    while (!((hits >> k) & 1u)) k++;
+    return k;
+}
 // apply_force_to_ball (RR_TrashyPhysics.py:88-152)
 template <class C> RR_HDN void apply_force_to_ball(Arena<C> &A, const SimParams<typename C::Real> &sp, int r, int b, uint32_t bots_moved, int &st) {
     using R = typename C::Real;
@@ -629,37 +687,30 @@ template <class C> RR_HDN void apply_force_to_ball(Arena<C> &A, const SimParams<
     force_diameters(A, r, bc, dia);
     R fx = A.bfx[b], fy = A.bfy[b];
     bool done = false;
-    #pragma unroll 1
-    for (int s = 0; s < 4 && !done; s++) {
-        Seg<R> side = robot_side(A, r, s);
-#pragma unroll 1
-        for (int d = 0; d < 2 && !done; d++) {
-            V2<R> I = line_intersection<R>(side, dia[d], st);
-            if (within<R>(I, side, (R)0) && within<R>(I, dia[d], cbuf)) {
-                R da = dist<R>(dia[d].a, rc), db = dist<R>(dia[d].b, rc);
-                V2<R> cp = (da < db) ? dia[d].a : dia[d].b, opp = (da >= db) ? dia[d].a : dia[d].b;
-                fx += (I.x - cp.x) + (opp.x - cp.x) * cbuf / (R)14;
-                fy += (I.y - cp.y) + (opp.y - cp.y) * cbuf / (R)14;
-                done = true;
-            }
-        }
-    }
-    if (!done) {
-        R px, py, prel[8];
-        robot_prev_frame(A, sp, r, bots_moved, px, py, prel);
-        #pragma unroll 1
-        for (int c = 0; c < 4 && !done; c++) {
+    const int k = first_surface_hit(A, r, dia, cbuf);
+    if (k >= 0) {
+        const int sd = k >> 1, d = k & 1;
+        Seg<R> side = robot_side(A, r, sd);
+        V2<R> I = line_intersection<R>(side, dia[d], st);
+        R da = dist<R>(dia[d].a, rc), db = dist<R>(dia[d].b, rc);
+        V2<R> cp = (da < db) ? dia[d].a : dia[d].b, opp = (da >= db) ? dia[d].a : dia[d].b;
+        fx += (I.x - cp.x) + (opp.x - cp.x) * cbuf / (R)14;
+        fy += (I.y - cp.y) + (opp.y - cp.y) * cbuf / (R)14;
+        done = true;
+    } else {
+        const int c = first_corner_hit(A, r, bc, (R)7 + cbuf);
+        if (c >= 0) {
+            R px, py, prel[8];
+            robot_prev_frame(A, sp, r, bots_moved, px, py, prel);
             V2<R> bcn = robot_corner(A, r, c);
             R dc = dist<R>(bcn, bc);
-            if (dc < (R)7 + cbuf) {
-                V2<R> pc = { px + prel[2 * c], py + prel[2 * c + 1] };
-                V2<R> con = { bc.x - (bcn.x * (R)3 + pc.x) / (R)4, bc.y - (bcn.y * (R)3 + pc.y) / (R)4 };
-                R cd = m_sqrt(con.x * con.x + con.y * con.y);
-                R ex = ((R)7 - dc) * (R)1.2;
-                fx += (con.x * ex / cd) + con.x * cbuf / cd;
-                fy += (con.y * ex / cd) + con.y * cbuf / cd;
-                done = true;
-            }
+            V2<R> pc = { px + prel[2 * c], py + prel[2 * c + 1] };
+            V2<R> con = { bc.x - (bcn.x * (R)3 + pc.x) / (R)4, bc.y - (bcn.y * (R)3 + pc.y) / (R)4 };
+            R cd = m_sqrt(con.x * con.x + con.y * con.y);
+            R ex = ((R)7 - dc) * (R)1.2;
+            fx += (con.x * ex / cd) + con.x * cbuf / cd;
+            fy += (con.y * ex / cd) + con.y * cbuf / cd;
+            done = true;
         }
     }
     if (done && RR_IS_LANE0) {
@@ -684,37 +735,30 @@ template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, const SimParams<
     V2<R> bc = { A.p.bcx[b], A.p.bcy[b] };
     Seg<R> dia[2];
     force_diameters(A, r, bc, dia);
-    R px, py, prel[8];
-    robot_prev_frame(A, sp, r, bots_moved, px, py, prel);
     R mvx = 0, mvy = 0;
     bool done = false;
-    #pragma unroll 1
-    for (int s = 0; s < 4 && !done; s++) {
-        Seg<R> side = robot_side(A, r, s);
-        int ca = side_a(s), cb = side_b(s);
-        Seg<R> sprev = { { px + prel[2 * ca], py + prel[2 * ca + 1] }, { px + prel[2 * cb], py + prel[2 * cb + 1] } };
-#pragma unroll 1
-        for (int d = 0; d < 2 && !done; d++) {
+    const int k = first_surface_hit(A, r, dia, (R)0);
+    const int c = (k >= 0) ? -1 : first_corner_hit(A, r, bc, (R)7);
+    if (k >= 0 || c >= 0) {
+        R px, py, prel[8];
+        robot_prev_frame(A, sp, r, bots_moved, px, py, prel);
+        if (k >= 0) {
+            const int sd = k >> 1, d = k & 1;
+            Seg<R> side = robot_side(A, r, sd);
+            const int ca = side_a(sd), cb = side_b(sd);
+            Seg<R> sprev = { { px + prel[2 * ca], py + prel[2 * ca + 1] }, { px + prel[2 * cb], py + prel[2 * cb + 1] } };
             V2<R> I = line_intersection<R>(side, dia[d], st);
-            if (within<R>(I, side, (R)0) && within<R>(I, dia[d], (R)0)) {
-                V2<R> Ip = line_intersection<R>(sprev, dia[d], st);
-                R da = dist<R>(dia[d].a, Ip), db = dist<R>(dia[d].b, Ip);
-                V2<R> cp = (da < db) ? dia[d].a : dia[d].b, opp = (da >= db) ? dia[d].a : dia[d].b;
-                V2<R> con = { opp.x - cp.x, opp.y - cp.y };
-                R d2;
-                bounce_reflect<R>(con, vx, vy, d2);
-                R sq = m_sqrt(d2);
-                mvx = (I.x - cp.x) + con.x * cbuf / sq;
-                mvy = (I.y - cp.y) + con.y * cbuf / sq;
-                done = true;
-            }
-        }
-    }
-    #pragma unroll 1
-    for (int c = 0; c < 4 && !done; c++) {
-        V2<R> bcn = robot_corner(A, r, c);
-        R dc = dist<R>(bcn, bc);
-        if (dc < (R)7) {
+            V2<R> Ip = line_intersection<R>(sprev, dia[d], st);
+            R da = dist<R>(dia[d].a, Ip), db = dist<R>(dia[d].b, Ip);
+            V2<R> cp = (da < db) ? dia[d].a : dia[d].b, opp = (da >= db) ? dia[d].a : dia[d].b;
+            V2<R> con = { opp.x - cp.x, opp.y - cp.y };
+            R d2;
+            bounce_reflect<R>(con, vx, vy, d2);
+            R sq = m_sqrt(d2);
+            mvx = (I.x - cp.x) + con.x * cbuf / sq;
+            mvy = (I.y - cp.y) + con.y * cbuf / sq;
+        } else {
+            V2<R> bcn = robot_corner(A, r, c);
             V2<R> pc = { px + prel[2 * c], py + prel[2 * c + 1] };
             V2<R> con = { bc.x - (bcn.x * (R)3 + pc.x) / (R)4, bc.y - (bcn.y * (R)3 + pc.y) / (R)4 };
             R d2;
@@ -722,8 +766,8 @@ template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, const SimParams<
             R ex = dist<R>(pc, bc), cd = m_sqrt(d2);
             mvx = con.x * ex / cd;
             mvy = con.y * ex / cd;
-            done = true;
         }
+        done = true;
     }
     if (done && RR_IS_LANE0) {
         A.p.bvx[b] = vx; A.p.bvy[b] = vy;
@@ -846,7 +890,6 @@ template <class C> RR_HDN void resolve_bot_collisions(Arena<C> &A, const SimPara
             }
             RR_SYNC();
         }
-        refresh_sides(A);
         pairs = detect_robot_pairs(A);
     }
 }
@@ -929,9 +972,14 @@ RR_HDN void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real>
                 if (l < C::NB && (uballs & (1u << l))) ball_undo_lane(A, l);
             }
             RR_SYNC();
-            if (ubots) refresh_sides(A);
         }
-        if (count > limit && naughty && !(ubots | uballs)) { st |= ST_UNDO_FAIL; return; }
+        if (naughty && !(ubots | uballs)) {
+            // nothing left to undo: every further iteration would find the same contacts and change nothing, so the
+            // reference ends the same way -- the raise after NB+NR iterations (GAME_MODE=False) or the warning
+            // followed by an endless loop (GAME_MODE=True).  Exit now with exactly those status bits.
+            st |= ST_UNDO_FAIL | (sp.game_mode ? ST_UNDO_WARN : 0);
+            return;
+        }
     }
 }
 
@@ -953,7 +1001,6 @@ template <class C> RR_HD void substep(Arena<C> &A, const SimParams<typename C::R
         if (l < C::NR) robot_move_lane(A, sp, l);
     }
     RR_SYNC();
-    refresh_sides(A);
     resolve_bot_collisions(A, sp, bots_moved, naughty, st);
     { // _push_balls (RR_EnvBase.py:335-339): frozen hit list, ball-major order
         uint32_t br = detect_ball_robot(A, sp);
@@ -990,6 +1037,7 @@ RR_HDN bool observe(Arena<C> &A, const SimParams<typename C::Real> &sp, int team
     if (bidx < 0) bidx = 0;
     RR_FOR_LANES(l) { if (l < C::NR) A.irot[l] = (R)NAN; } // the candidates below overwrite the aliased inner-square offsets
     RR_SYNC();
+    ensure_sides(A);
     // one lane per (ray, rect): minimum over the rect's four sides in registers, then over the rects below
     constexpr int NT = 3 * C::NR;
     for (int base = 0; base < NT; base += C::VW) {
@@ -1012,15 +1060,20 @@ RR_HDN bool observe(Arena<C> &A, const SimParams<typename C::Real> &sp, int team
 #pragma unroll 1
                 for (int s = 0; s < 4; s++) {
                     Seg<R> side;
+                    R ms, cs;
                     if (j < C::NR - 1) {
-                        side = robot_side(A, j < ridx ? j : j + 1, s);
+                        const int ro = j < ridx ? j : j + 1;
+                        side = robot_side(A, ro, s);
+                        ms = A.sm[ro][s]; cs = A.sc[ro][s];
                     } else { // rect_walls = FloatRect(0, W, 0, H) (RR_EnvBase.py:74): corner = centre + (+-W/2, +-H/2)
                         const int ca = side_a(s), cb = side_b(s);
                         side = { { hx + ((ca & 1) ? hx : -hx), hy + ((ca & 2) ? hy : -hy) },
                                  { hx + ((cb & 1) ? hx : -hx), hy + ((cb & 2) ? hy : -hy) } };
+                        // get_slope_yint of the wall sides, constant: RIGHT (W,0)->(W,H) +inf/-inf; TOP (0,0)->(W,0) 0/0;
+                        // LEFT (0,H)->(0,0) -inf/+inf; BOTTOM (W,H)->(0,H) -0.0 / H
+                        ms = s == 0 ? inf_<R>() : s == 2 ? -inf_<R>() : s == 1 ? (R)0 : (R)-0.0;
+                        cs = s == 0 ? -inf_<R>() : s == 2 ? inf_<R>() : s == 1 ? (R)0 : sp.H;
                     }
-                    R ms, cs;
-                    slope_yint<R>(side.a, side.b, ms, cs, lst);
                     V2<R> I = intersect_mb<R>(ms, cs, side.a.x, mr, cr, a.x);
                     R de = dist<R>(I, b), ds = dist<R>(I, a);
                     if (de <= ds && de < bf) bf = de;
@@ -1084,8 +1137,8 @@ template <class C> RR_HD void derive(Arena<C> &A, const SimParams<typename C::Re
             A.irot[l] = (R)NAN; // inner-square offsets are built lazily by the first narrow phase that needs them
         }
     }
+    if (RR_IS_LANE0) A.sides_ok = 0;
     RR_SYNC();
-    refresh_sides(A);
 }
 // "clean" robot pose: centre exactly (x,y), edges re-derived like the rotation setter, no history
 template <class C> RR_HD void robot_set_clean_lane(Arena<C> &A, const SimParams<typename C::Real> &sp, int r,
@@ -1148,7 +1201,7 @@ RR_HDN void reset_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint
     RR_FOR_LANES(l) {
         if (l < C::NR) robot_set_clean_lane(A, sp, l, A.p.rcx[l], A.p.rcy[l], l < C::NRH ? (R)90 : (R)-90);
         if (l < C::NB) { A.p.bvx[l] = (R)0; A.p.bvy[l] = (R)0; }
-        if (l == 0) { A.i.step = 0; A.i.episode = (int32_t)episode; A.i.ep_len = 0; A.p.acc[0] = (R)0; A.p.acc[1] = (R)0; }
+        if (l == 0) { A.i.step = 0; A.i.episode = (int32_t)episode; A.i.ep_len = 0; A.i.fault = 0; A.p.acc[0] = (R)0; A.p.acc[1] = (R)0; }
     }
     RR_SYNC();
     // robots not yet placed still block at their old pose (RR_EnvBase.py:157-158 writes sprite attrs only)
@@ -1209,7 +1262,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     using R = typename C::Real;
     int st = 0;
     // raw mode raises when stepping a finished game (:261-262); with auto_reset the call resets instead
-    if (sp.time_limit ? (A.i.step >= sp.game_len) : (A.i.step > sp.game_len)) {
+    if ((sp.time_limit ? (A.i.step >= sp.game_len) : (A.i.step > sp.game_len)) || A.i.fault) {
         if (sp.auto_reset) {
             reset_arena(A, sp, arena_gid, (uint64_t)(uint32_t)(A.i.episode + 1), st);
             st |= ST_WAS_RESET;
@@ -1292,7 +1345,9 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
         rew_g -= delta * sp.mult_ball;
     }
     const int step_now = A.i.step;
-    const bool done = is_done<R>(step_now, sp);
+    constexpr int ST_FATAL = ST_BOT_RESOLVE_FAIL | ST_BOT_STUCK | ST_UNDO_MOVE_FAIL | ST_UNDO_FAIL | ST_SAME_SPOT | ST_DIV0;
+    const bool faulted = sp.reset_on_fault && (st & ST_FATAL); // the reference raised (or hangs) inside this step
+    const bool done = is_done<R>(step_now, sp) || faulted;
     observe<C, O>(A, sp, 1, -1, -1, o.obs, st);
     if (o.obs_g) {
         if (!observe<C, O>(A, sp, -1, -1, -1, o.obs_g, st)) {
@@ -1306,6 +1361,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
         // episode bookkeeping for logging (the caller sums `score` the same way, Training_DQN_pytorch.py:345-346)
         A.p.acc[0] += rew_h; A.p.acc[1] += rew_g; A.i.ep_len += 1;
         if (done) { A.p.acc[2] = A.p.acc[0]; A.p.acc[3] = A.p.acc[1]; A.i.last_len = A.i.ep_len; A.i.ep_count += 1; }
+        if (faulted) A.i.fault = 1;
     }
     RR_SYNC();
 }

@@ -58,13 +58,15 @@ class BatchedRoboRugbyEnv:
     time_limit=True reports done when step_count == max_episode_steps like gym's TimeLimit wrapper does for the
     DQN script; False is the raw env rule (step_count > T, RR_EnvBase.py:555-559).  With auto_reset=True a step
     on a finished arena re-places it (status bit 1024, reward 0, done False, obs = first obs of the new episode)
-    instead of raising "Game is over" -- the policy's action for that arena is ignored on that call.
+    instead of raising "Game is over" -- the policy's action for that arena is ignored on that call.  With
+    reset_on_fault (default = auto_reset) a step in which the reference would have raised or hung
+    (info.status bits 1|2|4|8|16|32) also reports done=True, so faulted arenas are re-placed instead of lingering.
     """
     metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 30}
     reward_range = (-float("inf"), float("inf"))
 
     def __init__(self, num_envs, preset="T", device=None, seed=0, time_limit=True, auto_reset=True, dtype="f64",
-                 arena_offset=0, env_id="RoboRugbySimpleDuel-v3"):
+                 arena_offset=0, env_id="RoboRugbySimpleDuel-v3", reset_on_fault=None):
         self.preset = PRESETS[preset] if isinstance(preset, str) else preset
         assert isinstance(self.preset, Preset)
         if not torch.cuda.is_available():
@@ -76,12 +78,16 @@ class BatchedRoboRugbyEnv:
         self.num_envs = int(num_envs)
         self.dtype = dtype
         self.time_limit, self.auto_reset = bool(time_limit), bool(auto_reset)
+        # where the reference would raise / hang inside step() the episode ends (done=True + status bit) so that
+        # auto-reset re-places the arena; default: on exactly when auto_reset is
+        self.reset_on_fault = bool(auto_reset if reset_on_fault is None else reset_on_fault)
         p = self.preset
         self._lib = _lib.load()
         cfg = _lib.RRConfig(
             struct_size=C.sizeof(_lib.RRConfig), num_envs=self.num_envs, nr_happy=p.nr_happy, nr_grumpy=p.nr_grumpy,
             nb_pos=p.nb_pos, nb_neg=p.nb_neg, arena_w=p.arena_w, arena_h=p.arena_h, game_len_steps=p.game_len_steps,
             game_mode=int(p.game_mode), time_limit=int(self.time_limit), auto_reset=int(self.auto_reset),
+            reset_on_fault=int(self.reset_on_fault),
             dtype={"f64": 0, "f32": 1}[dtype], device=self.device.index or 0, seed=int(seed),
             arena_offset=int(arena_offset))
         h = C.c_void_p()

@@ -23,7 +23,8 @@ template <typename R> static void fill_params(SimParams<R> &sp, double W, double
     double hr = 7 * std::pow(2.0, .5) / 2;
     sp.inner_h = (R)hr;
     sp.inner_cdist = (R)std::pow(hr * hr + hr * hr, .5);
-    sp.game_len = game_len; sp.game_mode = game_mode; sp.time_limit = time_limit; sp.auto_reset = auto_reset;
+    sp.game_len = game_len; sp.game_mode = game_mode; sp.time_limit = time_limit; sp.auto_reset = auto_reset & 1;
+    sp.reset_on_fault = (auto_reset >> 1) & 1; // bit 1 of the flag word
     sp.seed = seed; sp.arena_offset = 0;
 }
 
@@ -42,6 +43,7 @@ template <class C> static void set_state(Emu<C> *e, const double *robots, const 
         A.p.bb[b] = (R)q[5]; A.p.bvx[b] = (R)q[6]; A.p.bvy[b] = (R)q[7];
     }
     A.i.step = step;
+    A.i.fault = 0;
     derive(A, e->sp);
 }
 template <class C> static void get_state(Emu<C> *e, double *robots, int32_t *ri, double *balls, int32_t *step) {

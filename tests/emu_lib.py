@@ -52,14 +52,14 @@ def _ip(a):
 
 
 class EmuEnv:
-    def __init__(self, preset="T", f32=False, time_limit=0, auto_reset=0, seed=0, narrow=False):
+    def __init__(self, preset="T", f32=False, time_limit=0, auto_reset=0, seed=0, narrow=False, reset_on_fault=0):
         cfg = ol.PRESETS[preset]
         self.cfg = cfg
         self.nr = cfg["nr_h"] + cfg["nr_g"]
         self.nb = cfg["nb_p"] + cfg["nb_n"]
         # narrow=True: fp64 with VW = 4 (T) / 16 (G) lanes per arena, i.e. multi-round phases as in the packed builds
         self.h = lib().emu_create(0 if preset == "T" else 1, 2 if narrow else int(f32), cfg["W"], cfg["H"], cfg["game_len"],
-                                  cfg["game_mode"], time_limit, auto_reset, seed)
+                                  cfg["game_mode"], time_limit, int(auto_reset) | (int(reset_on_fault) << 1), seed)
 
     def __del__(self):
         if getattr(self, "h", None):

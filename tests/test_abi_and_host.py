@@ -34,9 +34,10 @@ def test_library_exports_every_declared_symbol():
 
 def test_config_struct_matches_header_layout():
     from roborugby_amd import _lib
-    # 2+4 int32, 2 double, 6 int32, 2 uint64 with natural alignment = 80 bytes
-    assert C.sizeof(_lib.RRConfig) == 80
-    assert _lib.RRConfig.arena_w.offset == 24 and _lib.RRConfig.seed.offset == 64
+    # 2+4 int32, 2 double, 7 int32 (+4 pad), 2 uint64 with natural alignment = 88 bytes
+    assert C.sizeof(_lib.RRConfig) == 88
+    assert _lib.RRConfig.arena_w.offset == 24 and _lib.RRConfig.reset_on_fault.offset == 56
+    assert _lib.RRConfig.seed.offset == 72
 
 
 def test_presets_reproduce_reference_constants(golden_dir):

@@ -135,3 +135,23 @@ def test_f32_mode_single_step_error_distribution(golden_dir):
     assert np.median(errs) < 1e-5
     assert np.percentile(errs, 90) < 1e-4
     assert (errs > 1e-2).mean() < 0.01  # branch flips
+
+
+def test_reset_on_fault_ends_the_episode(golden_dir):
+    """Where the reference raised inside step(), reset_on_fault reports done=True and the next call re-places the arena."""
+    t = np.load(f"{golden_dir}/traj_T.npz")
+    eps = [ep for ep in range(t["length"].shape[0]) if int(t["exc"][ep])]
+    tg = np.load(f"{golden_dir}/traj_G.npz")
+    epg = [ep for ep in range(tg["length"].shape[0]) if int(tg["exc"][ep])]
+    assert epg
+    ep = epg[0]
+    n = int(tg["length"][ep])
+    a = tg["actions"][ep, n]
+    a = a[a >= 0]
+    for rof, want_done in ((0, False), (1, True)):
+        e = el.EmuEnv("G", auto_reset=1, reset_on_fault=rof, seed=3)
+        e.set_state(tg["state_robots"][ep, n], tg["state_robots_i"][ep, n], tg["state_balls"][ep, n], tg["state_step"][ep, n])
+        r = e.step(a)
+        assert r["status"] & int(tg["exc"][ep]) and r["done"] == want_done
+        r2 = e.step(a)
+        assert bool(r2["status"] & 1024) == want_done  # re-placed only under the policy

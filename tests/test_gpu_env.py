@@ -150,7 +150,7 @@ def test_determinism_and_shard_invariance_full_size():
     acts = torch.randint(0, 8, (6, n, 4), generator=gen, device="cuda", dtype=torch.int32)
 
     def run(num, offset, sl):
-        env = rr.BatchedRoboRugbyEnv(num, preset="G", seed=123, arena_offset=offset)
+        env = rr.BatchedRoboRugbyEnv(num, preset="G", seed=123, arena_offset=offset, reset_on_fault=False)
         outs = [env.reset()]
         for k in range(6):
             o, r, d, info = env.step(acts[k][sl])
@@ -211,3 +211,27 @@ def test_f32_mode_runs_and_tracks_f64():
     assert float(err.median()) < 1e-2 and float((err > 1.0).float().mean()) < 0.03
     with pytest.raises(Exception, match="RR_DTYPE_F32"):
         e32.step_f64(a)
+
+
+def test_reset_on_fault_replaces_faulted_arenas():
+    """Arenas whose spawn leaves a ball jammed against a robot fault on every step in the reference (it raises /
+    spins forever).  With reset_on_fault they are reported done once and re-placed; without it they linger."""
+    rr = _rr()
+    n = 65536
+    a = torch.full((n, 4), 8, dtype=torch.int32, device="cuda")  # invalid action: nobody moves
+    keep = rr.BatchedRoboRugbyEnv(n, preset="G", seed=0, reset_on_fault=False)
+    keep.reset()
+    for _ in range(3):
+        _, _, d_keep, i_keep = keep.step(a)
+    lingering = int(((i_keep.status & 63) != 0).sum())
+    assert lingering > 0 and not bool(d_keep.any())
+    env = rr.BatchedRoboRugbyEnv(n, preset="G", seed=0)  # default: reset_on_fault follows auto_reset
+    env.reset()
+    _, _, d1, i1 = env.step(a)
+    f1 = (i1.status & 63) != 0  # fatal bits: the reference raised or hangs
+    assert int(f1.sum()) == lingering and torch.equal(d1, f1)
+    _, _, d2, i2 = env.step(a)
+    assert bool(((i2.status & 1024) != 0)[f1].all()) and not bool(d2[f1].any())
+    for _ in range(4):
+        _, _, d3, i3 = env.step(a)
+    assert int(((i3.status & 63) != 0).sum()) < max(2, lingering // 4)
