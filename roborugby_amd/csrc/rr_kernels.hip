@@ -1,10 +1,10 @@
 // rr_kernels.hip -- gfx950 kernels + the C-ABI (include/roborugby_amd.h) of the batched RoboRugby simulator.
 //
-// Launch geometry: 256-thread workgroups = 4 wavefronts; a wavefront is cut into 64/VW virtual waves of VW
+// Launch geometry: 64-thread workgroups = 1 wavefront; a wavefront is cut into 64/VW virtual waves of VW
 // lanes and every virtual wave owns one arena (VW = 64: one wavefront per arena; VW = 16: four arenas per
 // wavefront, ...).  Each arena has a private LDS slice (Arena<C>) and never talks to another arena, so there
 // is no workgroup barrier anywhere and no inter-workgroup traffic -- any blockIdx -> XCD placement is equally
-// good (arenas share nothing, there is no L2 reuse to protect).  65,536 arenas = 1,024..16,384 workgroups.
+// good (arenas share nothing, there is no L2 reuse to protect).  65,536 arenas = 2,048..65,536 workgroups.
 //
 // HBM layout: one record of P_STRIDE reals + one of I_STRIDE int32 per arena, both padded to 128-B
 // multiples.  Inside a record the fields are entity-minor (SoA over robots / balls), and a wave
@@ -44,7 +44,10 @@ template <class C> __device__ __forceinline__ void store_record(const Arena<C> &
     for (int k = lane; k < Arena<C>::I_INTS; k += C::VW) irec[k] = q[k];
 }
 
-constexpr int WAVES_PER_BLOCK = 4;
+#ifndef RR_WAVES_PER_BLOCK
+#define RR_WAVES_PER_BLOCK 1 // arenas never cooperate across wavefronts, so a workgroup IS a wavefront (finer dispatch: +9 % measured)
+#endif
+constexpr int WAVES_PER_BLOCK = RR_WAVES_PER_BLOCK;
 template <class C> constexpr int arenas_per_block() { return 64 * WAVES_PER_BLOCK / C::VW; }
 #ifndef RR_MIN_WAVES_PER_SIMD
 #define RR_MIN_WAVES_PER_SIMD 4 // <=128 VGPRs: 4 waves/SIMD measured 4x faster than the 1 wave/SIMD the allocator picks unconstrained
