@@ -65,13 +65,17 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, RR_MIN_WAVES_PER_SIMD) void k
     Arena<C> &A = lds[wave];
     typename C::Real *rec = recs + (size_t)arena * Arena<C>::P_STRIDE;
     int32_t *irec = irecs + (size_t)arena * Arena<C>::I_STRIDE;
+    RR_T0();
     load_record(A, rec, irec);
     derive(A, sp);
+    RR_STAMP(12);
     StepOut<O> o = { obs + (size_t)arena * 11, obs_g ? obs_g + (size_t)arena * 11 : nullptr, reward + arena,
                      reward_g ? reward_g + arena : nullptr, done + arena, status ? status + arena : nullptr };
     step_arena<C, O>(A, sp, sp.arena_offset + (uint64_t)arena, actions ? actions + (size_t)arena * na : nullptr,
                      thrust ? thrust + (size_t)arena * 2 * na : nullptr, na, o);
+    RR_TR();
     store_record(A, rec, irec);
+    RR_STAMP(13);
 }
 
 // env.reset() for masked arenas; also used (init = 1) to build the constructor's state
@@ -511,5 +515,17 @@ int rr_lanes_per_env(const rr_env *e, int32_t *lanes) {
     *lanes = e->vw;
     return 0;
 }
+
+#ifdef RR_PROFILE_PHASES
+// diagnostic build only: copy out / clear the per-phase cycle totals
+int rr_debug_phase_cycles(unsigned long long *host32, int clear) {
+    if (hipMemcpyFromSymbol(host32, HIP_SYMBOL(g_rr_prof), 32 * sizeof(unsigned long long)) != hipSuccess) return -2;
+    if (clear) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_rr_prof), z, sizeof z) != hipSuccess) return -2;
+    }
+    return 0;
+}
+#endif
 
 } // extern "C"

@@ -67,6 +67,26 @@
 #define RR_VOTE(mask, l, pred) (mask) |= ((uint64_t)((pred) ? 1 : 0)) << (l)
 #endif
 
+// Diagnostic build only (-DRR_PROFILE_PHASES): per-phase cycle totals of wave-leader lanes, accumulated with atomics
+// into a device array that tools/phase_profile.py reads.  Never compiled into the product library.
+#if defined(__HIPCC__) && defined(RR_PROFILE_PHASES)
+__device__ unsigned long long g_rr_prof[32];
+#endif
+#if RR_GPU && defined(RR_PROFILE_PHASES)
+#define RR_T0() unsigned long long rr_t0_ = __builtin_amdgcn_s_memtime()
+#define RR_TR() rr_t0_ = __builtin_amdgcn_s_memtime()
+#define RR_STAMP(id)                                                                          \
+    do {                                                                                      \
+        unsigned long long rr_t1_ = __builtin_amdgcn_s_memtime();                             \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_rr_prof[id], rr_t1_ - rr_t0_);              \
+        rr_t0_ = rr_t1_;                                                                      \
+    } while (0)
+#else
+#define RR_T0() do { } while (0)
+#define RR_TR() do { } while (0)
+#define RR_STAMP(id) do { } while (0)
+#endif
+
 namespace rr {
 
 #if RR_GPU
@@ -287,23 +307,25 @@ template <typename R> RR_HD void fr_set_cy(FR<R> &f, R v) { fr_move<R>(f, (R)0, 
 
 // body of the rotation setter (MyUtils.py:284-316): rotate the initial corners (+-hw, +-hh) by
 // 360-rot degrees and renormalise them to the corner distance
-template <typename R> RR_HD void corners_for(R rot, R hw, R hh, R cdist, R *rel) {
+template <typename R> RR_HD void corners_from_sc(R rot, R s, R c, R hw, R hh, R cdist, R *rel) {
     // initial corners TL(-hw,-hh) TR(hw,-hh) BL(-hw,hh) BR(hw,hh): BR = -TL and BL = -TR, and every operation
     // below is odd-symmetric in (x,y), so two corners are computed and two are exact negations
-    if (rot == (R)0) {
-        rel[0] = -hw; rel[1] = -hh; rel[2] = hw; rel[3] = -hh; rel[4] = -hw; rel[5] = hh; rel[6] = hw; rel[7] = hh;
-        return;
-    }
-    R c, s;
-    m_sincos(radians<R>((R)360 - rot), s, c);
+    // (s, c) = sin/cos of radians(360 - rot); rot == 0 keeps the initial corners (MyUtils.py:298-300)
     const R ix[2] = { -hw, hw }, iy = -hh; // TL, TR
     for (int k = 0; k < 2; k++) {
         R qx = ix[k] * c - iy * s, qy = ix[k] * s + iy * c;
         R d = m_sqrt(qx * qx + qy * qy);
         R ax = qx * cdist / d, ay = qy * cdist / d;
+        const bool z = rot == (R)0;
+        ax = z ? ix[k] : ax; ay = z ? iy : ay;
         rel[2 * k] = ax; rel[2 * k + 1] = ay;                  // TL / TR
         rel[2 * (3 - k)] = -ax; rel[2 * (3 - k) + 1] = -ay;    // BR / BL
     }
+}
+template <typename R> RR_HD void corners_for(R rot, R hw, R hh, R cdist, R *rel) {
+    R c, s;
+    m_sincos(radians<R>((R)360 - rot), s, c);
+    corners_from_sc<R>(rot, s, c, hw, hh, cdist, rel);
 }
 template <typename R> RR_HD void fr_edges_from_rel(FR<R> &f) { // MyUtils.py:318-322
     R mnx = f.rel[0], mxx = f.rel[0], mny = f.rel[1], mxy = f.rel[1];
@@ -387,25 +409,49 @@ template <typename R> RR_HD void rob_move_angular(FR<R> &f, const SimParams<R> &
     }
     rob_clamp<R>(f, sp);
 }
+// Robot.move (RR_Robot.py:106-108,139-234).  Lanes of one wavefront drive robots with different thrust patterns; the
+// three trig evaluations a move can need (heading or pivot direction, the rotation setter's 360-rot, the re-centring
+// angle) are independent of each other, so they are issued up front as straight-line code -- one latency instead
+// of three serialised divergent paths -- and the cheap bookkeeping then selects what its move type uses.  Every
+// value is computed from the same operands in the same order as rob_move_linear / rob_move_angular above.
 template <class C> RR_HD void robot_move_lane(Arena<C> &A, const SimParams<typename C::Real> &sp, int r) {
     using R = typename C::Real;
     const int L = A.i.thl[r], Rt = A.i.thr[r];
     A.i.mc[r] += 1;
     if (L == Rt && L == 0) return;
     FR<R> f = load_robot(A, r);
-    if (L == Rt) {
-        rob_move_linear<R>(f, sp, L < 0 ? (R)-1 : (R)1);
-    } else if (L + Rt == 0) {
-        V2<R> z = { (R)0, (R)0 };
-        rob_move_angular<R>(f, sp, Rt > 0 ? (R)1.2 : (R)-1.2, false, z, (R)0);
+    const bool lin = (L == Rt);
+    const bool spin = !lin && (L + Rt == 0);
+    const R w = lin ? (R)0 : spin ? (Rt > 0 ? (R)1.2 : (R)-1.2) : ((Rt > 0 || L < 0) ? (R).6 : (R)-.6);
+    const R off = (Rt != 0) ? (R)90 : (R)-90; // pivot = left track (rot+90) when the right one drives
+    const R nrot = lin ? f.rot : py_mod<R>((f.rot + w) + (R)720, (R)360);
+    R s1, c1, s2, c2, s3, c3;
+    m_sincos(radians<R>(lin ? f.rot : f.rot + off), s1, c1); // heading (linear) / direction of the pivot (track) centre
+    m_sincos(radians<R>((R)360 - nrot), s2, c2);              // rotation setter
+    m_sincos(radians<R>(nrot + -off), s3, c3);                // robot centre as seen from the pivot after the turn
+    const R rot_prior = f.rot, px = f.cx, py = f.cy;
+    if (lin) {
+        const R vel = L < 0 ? (R)-1 : (R)1;
+        fr_set_left<R>(f, f.l + c1 * vel);
+        fr_set_top<R>(f, f.t + s1 * vel * (R)-1);
+        if (rob_hit_wall<R>(f, sp)) { fr_set_cx<R>(f, px); fr_set_cy<R>(f, py); }
     } else {
-        R w = (Rt > 0 || L < 0) ? (R).6 : (R)-.6;
-        R off = (Rt != 0) ? (R)90 : (R)-90; // pivot = left track (rot+90) when the right one drives
-        R sn, cs;
-        m_sincos(radians<R>(f.rot + off), sn, cs);
-        V2<R> c = { f.cx + (R)16 * cs, f.cy - (R)16 * sn };
-        rob_move_angular<R>(f, sp, w, true, c, -off);
+        if (nrot != f.rot) {
+            f.rot = nrot;
+            corners_from_sc<R>(nrot, s2, c2, (R)10, (R)20, sp.rob_cdist, f.rel);
+            fr_edges_from_rel<R>(f);
+        }
+        if (!spin) {
+            const R cpx = px + (R)16 * c1, cpy = py - (R)16 * s1; // tplCenterRot, from the pose before the turn
+            fr_set_cx<R>(f, cpx + (R)16 * c3);
+            fr_set_cy<R>(f, cpy - (R)16 * s3);
+        }
+        if (rob_hit_wall<R>(f, sp)) {
+            fr_set_cx<R>(f, px); fr_set_cy<R>(f, py);
+            fr_set_rot<R>(f, rot_prior, sp.rob_cdist);
+        }
     }
+    rob_clamp<R>(f, sp);
     store_robot(A, r, f);
 }
 // Robot.undo_move (RR_Robot.py:110-137): back to the pose stored at frame begin
@@ -983,26 +1029,56 @@ RR_HDN void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real>
     }
 }
 
-// one of the 12 physics sub-steps ("frame", RR_EnvBase.py:275-287)
-template <class C> RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &naughty, int &st) {
+// one of the 12 physics sub-steps ("frame", RR_EnvBase.py:275-287).
+// Wall time per sub-step is set by the number of dependent phases (LDS round trip + ballot each), not by their
+// arithmetic, so the common no-contact path is folded into four phases: [frame hooks + robot moves],
+// [robot-robot + ball-robot broad phase], [roll], [ball-ball + ball-robot broad phase + wall test].  Only when a
+// ballot reports something close do the reference-shaped loops below (unchanged, exact) run.
+// `prev_moved`: robots whose move of the previous sub-step survived (their ring entry moveCount-1 is that frame's).
+template <class C>
+RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &naughty, int &st, uint32_t &prev_moved) {
     using R = typename C::Real;
     uint32_t bots_moved = (1u << C::NR) - 1, balls_moved = (1u << C::NB) - 1;
-    RR_FOR_LANES(l) { // on_frame_begin (RR_Robot.py:119-120, RR_Ball.py:63-68)
+    RR_T0();
+    RR_FOR_LANES(l) {
         if (l < C::NR) {
+            if (prev_moved & (1u << l)) { A.p.px[l] = A.ax[l]; A.p.py[l] = A.ay[l]; A.p.prot[l] = A.arot[l]; }
+            // on_frame_begin (RR_Robot.py:119-120): the ring entry written this frame
             A.ax[l] = A.p.rcx[l]; A.ay[l] = A.p.rcy[l]; A.arot[l] = A.p.rrot[l];
+            robot_move_lane(A, sp, l); // _move_bots
         }
-        if (l < C::NB) {
+        if (l < C::NB) { // on_frame_begin (RR_Ball.py:63-68)
             A.bmass[l] = 1; A.bfx[l] = (R)0; A.bfy[l] = (R)0;
             A.pfx[l] = ball_copy_c<R>(A.p.bcx[l]); A.pfy[l] = ball_copy_c<R>(A.p.bcy[l]);
         }
     }
     RR_SYNC();
-    RR_FOR_LANES(l) { // _move_bots
-        if (l < C::NR) robot_move_lane(A, sp, l);
+    RR_STAMP(1);
+    // fused exact broad phase: robot lanes against the later robots, ball lanes against every robot
+    uint64_t m_rr = 0, m_br = 0;
+    RR_FOR_LANES(l) {
+        bool c_rr = false, c_br = false;
+        if (l < C::NR) {
+            for (int j = 0; j < C::NR; j++) {
+                R dx = A.p.rcx[j] - A.p.rcx[l], dy = A.p.rcy[j] - A.p.rcy[l];
+                c_rr = c_rr | ((j > l) & (dx * dx + dy * dy <= cull_rr2<R>()));
+            }
+        }
+        if (l < C::NB) {
+            for (int r = 0; r < C::NR; r++) {
+                R dx = A.p.bcx[l] - A.p.rcx[r], dy = A.p.bcy[l] - A.p.rcy[r];
+                c_br = c_br | (dx * dx + dy * dy <= cull_br2<R>());
+            }
+        }
+        RR_VOTE(m_rr, l, c_rr);
+        RR_VOTE(m_br, l, c_br);
     }
-    RR_SYNC();
-    resolve_bot_collisions(A, sp, bots_moved, naughty, st);
-    { // _push_balls (RR_EnvBase.py:335-339): frozen hit list, ball-major order
+    if (m_rr) {
+        resolve_bot_collisions(A, sp, bots_moved, naughty, st);
+        m_br = 1; // an undone robot changes the ball-robot picture: let the full detection decide
+    }
+    RR_STAMP(2);
+    if (m_br) { // _push_balls (RR_EnvBase.py:335-339): frozen hit list, ball-major order
         uint32_t br = detect_ball_robot(A, sp);
 #pragma unroll 1
         for (int p = 0; p < C::NB * C::NR; p++) {
@@ -1011,15 +1087,42 @@ template <class C> RR_HD void substep(Arena<C> &A, const SimParams<typename C::R
             bounce_ball_off_bot(A, sp, p % C::NR, p / C::NR, bots_moved, st);
         }
     }
+    RR_STAMP(3);
     RR_FOR_LANES(l) { // _roll_balls
         if (l < C::NB) ball_move_lane(A, l);
     }
     RR_SYNC();
-    if (!resolve_ball_collisions(A, sp, bots_moved, st)) undo_naughty_movement(A, sp, balls_moved, bots_moved, st);
-    RR_FOR_LANES(l) { // the ring entry moveCount-1 of a robot whose move survived is this frame's entry
-        if (l < C::NR && (bots_moved & (1u << l))) {
-            A.p.px[l] = A.ax[l]; A.p.py[l] = A.ay[l]; A.p.prot[l] = A.arot[l];
+    RR_STAMP(4);
+    // fused first pass of _resolve_ball_collisions: anything possibly touching?  (ball-ball within the sqrt test's
+    // reach, ball-robot within the broad-phase bound, the exact int-rect wall test)
+    uint64_t m_any = 0;
+    RR_FOR_LANES(l) {
+        bool c = false;
+        if (l < C::NB) {
+            for (int j = 0; j < C::NB; j++) {
+                R dx = A.p.bcx[j] - A.p.bcx[l], dy = A.p.bcy[j] - A.p.bcy[l];
+                c = c | ((j > l) & (dx * dx + dy * dy <= (R)197));
+            }
+            for (int r = 0; r < C::NR; r++) {
+                R dx = A.p.bcx[l] - A.p.rcx[r], dy = A.p.bcy[l] - A.p.rcy[r];
+                c = c | (dx * dx + dy * dy <= cull_br2<R>());
+            }
+            c = c | ball_collided_wall(A, sp, l);
         }
+        RR_VOTE(m_any, l, c);
+    }
+    if (m_any) { // the reference's loop, from its first pass (nothing has changed since the broad phase above)
+        bool rr_ok_ = resolve_ball_collisions(A, sp, bots_moved, st);
+        RR_STAMP(5);
+        if (!rr_ok_) undo_naughty_movement(A, sp, balls_moved, bots_moved, st);
+    }
+    RR_STAMP(6);
+    prev_moved = bots_moved;
+}
+// after the last sub-step: the pose-ring bookkeeping the next sub-step would have done
+template <class C> RR_HD void substeps_end(Arena<C> &A, uint32_t prev_moved) {
+    RR_FOR_LANES(l) {
+        if (l < C::NR && (prev_moved & (1u << l))) { A.p.px[l] = A.ax[l]; A.p.py[l] = A.ay[l]; A.p.prot[l] = A.arot[l]; }
     }
     RR_SYNC();
 }
@@ -1293,6 +1396,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
         }
         return;
     }
+    RR_T0();
     // ---- on_step_begin (:264-265; sprites, then the score keepers RR_ScoreKeepers.py:30-33,119-121,145-147)
     R dist_sum0 = (R)0;
     {
@@ -1320,8 +1424,12 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     if (!thrust) for (int q = 0; q < na && q < C::NR; q++) { int a = actions[q]; if (a < 0 || a > 7) st |= ST_BAD_ACTION; }
     RR_SYNC();
     uint32_t naughty = 0;
+    RR_STAMP(8);
+    uint32_t prev_moved = 0;
 #pragma unroll 1
-    for (int f = 0; f < 12; f++) substep(A, sp, naughty, st); // MOVES_PER_FRAME
+    for (int f = 0; f < 12; f++) substep(A, sp, naughty, st, prev_moved); // MOVES_PER_FRAME
+    substeps_end(A, prev_moved);
+    RR_STAMP(9);
     // ---- on_step_end: NaughtyBots, ChasePosBall, PushPosBallsToGoal (SURVEY 3.1 accumulation order)
     R rew_h = (R)0, rew_g = (R)0;
     for (int r = 0; r < C::NR; r++) if (naughty & (1u << r)) { if (r < C::NRH) rew_h -= (R).005; else rew_g -= (R).005; }
@@ -1344,6 +1452,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
         rew_h += delta * sp.mult_ball;
         rew_g -= delta * sp.mult_ball;
     }
+    RR_STAMP(10);
     const int step_now = A.i.step;
     constexpr int ST_FATAL = ST_BOT_RESOLVE_FAIL | ST_BOT_STUCK | ST_UNDO_MOVE_FAIL | ST_UNDO_FAIL | ST_SAME_SPOT | ST_DIV0;
     const bool faulted = sp.reset_on_fault && (st & ST_FATAL); // the reference raised (or hangs) inside this step
@@ -1364,6 +1473,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
         if (faulted) A.i.fault = 1;
     }
     RR_SYNC();
+    RR_STAMP(11);
 }
 
 } // namespace rr
