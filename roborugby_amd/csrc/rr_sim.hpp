@@ -1160,7 +1160,7 @@ RR_HDN bool observe(Arena<C> &A, const SimParams<typename C::Real> &sp, int team
                 slope_yint<R>(a, b, mr, cr, lst);
                 R bf = inf_<R>(), bb = inf_<R>();
                 const R hx = sp.W / (R)2, hy = sp.H / (R)2;
-#pragma unroll 1
+#pragma unroll
                 for (int s = 0; s < 4; s++) {
                     Seg<R> side;
                     R ms, cs;
@@ -1398,12 +1398,18 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     }
     RR_T0();
     // ---- on_step_begin (:264-265; sprites, then the score keepers RR_ScoreKeepers.py:30-33,119-121,145-147)
-    R dist_sum0 = (R)0;
-    {
-        V2<R> o0 = { (R)0, (R)0 };
-#pragma unroll 1
-        for (int b = 0; b < C::NBP; b++) { V2<R> c = { A.p.bcx[b], A.p.bcy[b] }; dist_sum0 = dist_sum0 + dist<R>(o0, c); }
+    static_assert(C::NBP + C::NR * C::NBP <= 2 * 3 * C::NR, "reward scratch reuses the lidar slots");
+    // _calc_ball_dist_sum (RR_ScoreKeepers.py:155-157): one lane per positive ball, summed in list order below
+    for (int base = 0; base < C::NBP; base += C::VW) {
+        RR_FOR_LANES(l) {
+            const int b = base + l;
+            if (b < C::NBP) { V2<R> o0 = { (R)0, (R)0 }, c = { A.p.bcx[b], A.p.bcy[b] }; A.u.lidar[1][b] = dist<R>(o0, c); }
+        }
     }
+    RR_SYNC();
+    R dist_sum0 = (R)0;
+    for (int b = 0; b < C::NBP; b++) dist_sum0 = dist_sum0 + A.u.lidar[1][b];
+    RR_SYNC();
     RR_FOR_LANES(l) {
         if (l < C::NR) {
             A.psx[l] = A.p.rcx[l]; A.psy[l] = A.p.rcy[l];
@@ -1431,27 +1437,35 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     substeps_end(A, prev_moved);
     RR_STAMP(9);
     // ---- on_step_end: NaughtyBots, ChasePosBall, PushPosBallsToGoal (SURVEY 3.1 accumulation order)
-    R rew_h = (R)0, rew_g = (R)0;
-    for (int r = 0; r < C::NR; r++) if (naughty & (1u << r)) { if (r < C::NRH) rew_h -= (R).005; else rew_g -= (R).005; }
-#pragma unroll 1
-    for (int r = 0; r < C::NR; r++) {
-        V2<R> rc = { A.p.rcx[r], A.p.rcy[r] }, pc = { A.psx[r], A.psy[r] };
-#pragma unroll 1
-        for (int b = 0; b < C::NBP; b++) {
-            V2<R> bc = { A.p.bcx[b], A.p.bcy[b] };
-            R now = dist<R>(rc, bc), prior = dist<R>(pc, bc);
-            if (r < C::NRH) rew_h += (prior - now) * sp.mult_robot; else rew_g += (prior - now) * sp.mult_robot;
+    // one lane per (robot, positive ball) ChasePosBall term and per positive ball distance; the sums keep list order
+    for (int base = 0; base < C::NR * C::NBP; base += C::VW) {
+        RR_FOR_LANES(l) {
+            const int t = base + l;
+            if (t < C::NR * C::NBP) {
+                const int r = t / C::NBP, b = t % C::NBP;
+                V2<R> rc = { A.p.rcx[r], A.p.rcy[r] }, pc = { A.psx[r], A.psy[r] }, bc = { A.p.bcx[b], A.p.bcy[b] };
+                R now = dist<R>(rc, bc), prior = dist<R>(pc, bc);
+                (&A.u.lidar[0][0])[C::NBP + t] = (prior - now) * sp.mult_robot;
+            }
+            if (t < C::NBP) { V2<R> o0 = { (R)0, (R)0 }, c = { A.p.bcx[t], A.p.bcy[t] }; (&A.u.lidar[0][0])[t] = dist<R>(o0, c); }
         }
     }
+    RR_SYNC();
+    R rew_h = (R)0, rew_g = (R)0;
+    for (int r = 0; r < C::NR; r++) if (naughty & (1u << r)) { if (r < C::NRH) rew_h -= (R).005; else rew_g -= (R).005; }
+    for (int r = 0; r < C::NR; r++)
+        for (int b = 0; b < C::NBP; b++) {
+            R term = (&A.u.lidar[0][0])[C::NBP + r * C::NBP + b];
+            if (r < C::NRH) rew_h += term; else rew_g += term;
+        }
     {
         R s1 = (R)0;
-        V2<R> o0 = { (R)0, (R)0 };
-#pragma unroll 1
-        for (int b = 0; b < C::NBP; b++) { V2<R> c = { A.p.bcx[b], A.p.bcy[b] }; s1 = s1 + dist<R>(o0, c); }
+        for (int b = 0; b < C::NBP; b++) s1 = s1 + (&A.u.lidar[0][0])[b];
         R delta = s1 - dist_sum0;
         rew_h += delta * sp.mult_ball;
         rew_g -= delta * sp.mult_ball;
     }
+    RR_SYNC(); // observe() reuses the scratch
     RR_STAMP(10);
     const int step_now = A.i.step;
     constexpr int ST_FATAL = ST_BOT_RESOLVE_FAIL | ST_BOT_STUCK | ST_UNDO_MOVE_FAIL | ST_UNDO_FAIL | ST_SAME_SPOT | ST_DIV0;
