@@ -262,6 +262,15 @@ template <class F> static int dispatch(const rr_env *e, F &&f) {
 #undef X
     return fail(-1, "corrupt handle");
 }
+// The caller's current HIP device is left as found; launches go to the device the handle was created on.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int want) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != want) switched = (hipSetDevice(want) == hipSuccess);
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
 template <class C> static dim3 arena_grid(int n) { return dim3((unsigned)((n + arenas_per_block<C>() - 1) / arenas_per_block<C>())); }
 static inline dim3 wave_block() { return dim3(64 * WAVES_PER_BLOCK); }
 
@@ -342,6 +351,7 @@ int rr_destroy(rr_env *e) {
 int rr_reset(rr_env *e, const uint8_t *mask, float *obs, float *obs_g, void *stream) {
     if (!e) return fail(-1, "rr_reset: null handle");
     const int n = e->cfg.num_envs;
+    DeviceGuard guard(e->cfg.device);
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
         hipLaunchKernelGGL((k_reset<CC, float>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
@@ -366,6 +376,7 @@ int rr_step(rr_env *e, const int32_t *actions, int32_t na, float *obs, float *re
             float *reward_g, int32_t *status, void *stream) {
     if (int rc = check_step_args(e, actions, na, obs, reward, done)) return rc;
     const int n = e->cfg.num_envs;
+    DeviceGuard guard(e->cfg.device);
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
         hipLaunchKernelGGL((k_step<CC, float>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
@@ -382,6 +393,7 @@ int rr_step_thrust(rr_env *e, const float *thrust, int32_t nk, float *obs, float
                    float *reward_g, int32_t *status, void *stream) {
     if (int rc = check_step_args(e, thrust, nk, obs, reward, done)) return rc;
     const int n = e->cfg.num_envs;
+    DeviceGuard guard(e->cfg.device);
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
         hipLaunchKernelGGL((k_step<CC, float>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
@@ -398,6 +410,7 @@ int rr_step_f64(rr_env *e, const int32_t *actions, int32_t na, double *obs, doub
                 double *reward_g, int32_t *status, void *stream) {
     if (int rc = check_step_args(e, actions, na, obs, reward, done)) return rc;
     const int n = e->cfg.num_envs;
+    DeviceGuard guard(e->cfg.device);
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
         if constexpr (std::is_same<RR, double>::value) {
@@ -423,6 +436,7 @@ static int check_obs_args(rr_env *e, const void *obs, int32_t team, int32_t ridx
 int rr_observe(rr_env *e, int32_t team, int32_t ridx, int32_t bidx, float *obs, void *stream) {
     if (int rc = check_obs_args(e, obs, team, ridx, bidx)) return rc;
     const int n = e->cfg.num_envs;
+    DeviceGuard guard(e->cfg.device);
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
         hipLaunchKernelGGL((k_observe<CC, float>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
@@ -436,6 +450,7 @@ int rr_observe(rr_env *e, int32_t team, int32_t ridx, int32_t bidx, float *obs, 
 int rr_observe_f64(rr_env *e, int32_t team, int32_t ridx, int32_t bidx, double *obs, void *stream) {
     if (int rc = check_obs_args(e, obs, team, ridx, bidx)) return rc;
     const int n = e->cfg.num_envs;
+    DeviceGuard guard(e->cfg.device);
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
         if constexpr (std::is_same<RR, double>::value) {
@@ -455,6 +470,7 @@ int rr_observe_f64(rr_env *e, int32_t team, int32_t ridx, int32_t bidx, double *
 int rr_set_state(rr_env *e, const double *robots, const int32_t *ri, const double *balls, const int32_t *step, void *stream) {
     if (!e || !robots || !ri || !balls || !step) return fail(-1, "rr_set_state: null argument");
     const int n = e->cfg.num_envs;
+    DeviceGuard guard(e->cfg.device);
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
         hipLaunchKernelGGL((k_set_state<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (RR *)e->recs, e->irecs,
@@ -468,6 +484,7 @@ int rr_set_state(rr_env *e, const double *robots, const int32_t *ri, const doubl
 int rr_get_state(rr_env *e, double *robots, int32_t *ri, double *balls, int32_t *step, void *stream) {
     if (!e || !robots || !ri || !balls || !step) return fail(-1, "rr_get_state: null argument");
     const int n = e->cfg.num_envs;
+    DeviceGuard guard(e->cfg.device);
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
         hipLaunchKernelGGL((k_get_state<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const RR *)e->recs,
@@ -481,6 +498,7 @@ int rr_get_state(rr_env *e, double *robots, int32_t *ri, double *balls, int32_t 
 int rr_set_poses(rr_env *e, const double *rxyr, const double *bxyv, void *stream) {
     if (!e || !rxyr || !bxyv) return fail(-1, "rr_set_poses: null argument");
     const int n = e->cfg.num_envs;
+    DeviceGuard guard(e->cfg.device);
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
         hipLaunchKernelGGL((k_set_poses<CC>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
@@ -494,6 +512,7 @@ int rr_set_poses(rr_env *e, const double *rxyr, const double *bxyv, void *stream
 int rr_episode_stats(rr_env *e, float *lr, float *lrg, int32_t *ll, int32_t *cnt, void *stream) {
     if (!e) return fail(-1, "rr_episode_stats: null handle");
     const int n = e->cfg.num_envs;
+    DeviceGuard guard(e->cfg.device);
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
         hipLaunchKernelGGL((k_episode_stats<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const RR *)e->recs,

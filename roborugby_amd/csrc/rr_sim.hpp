@@ -105,15 +105,11 @@ enum : int {
 };
 
 // ------------------------------------------------------------------------------------------------ math
-RR_HD double m_sin(double x) { return ::sin(x); }
-RR_HD double m_cos(double x) { return ::cos(x); }
 RR_HD double m_atan(double x) { return ::atan(x); }
 RR_HD double m_sqrt(double x) { return ::sqrt(x); }
 RR_HD double m_fmod(double a, double b) { return ::fmod(a, b); }
 RR_HD double m_abs(double x) { return ::fabs(x); }
 RR_HD double m_rint(double x) { return ::rint(x); }
-RR_HD float m_sin(float x) { return ::sinf(x); }
-RR_HD float m_cos(float x) { return ::cosf(x); }
 RR_HD float m_atan(float x) { return ::atanf(x); }
 RR_HD float m_sqrt(float x) { return ::sqrtf(x); }
 RR_HD float m_fmod(float a, float b) { return ::fmodf(a, b); }
@@ -385,35 +381,12 @@ template <typename R> RR_HD void rob_clamp(FR<R> &f, const SimParams<R> &sp) {
     if (f.t <= (R)0) fr_set_top<R>(f, buffer);
     if (f.b >= sp.H) fr_set_bottom<R>(f, sp.H - buffer);
 }
-template <typename R> RR_HD void rob_move_linear(FR<R> &f, const SimParams<R> &sp, R vel) {
-    R sn, cs;
-    m_sincos(radians<R>(f.rot), sn, cs);
-    R px = f.cx, py = f.cy;
-    fr_set_left<R>(f, f.l + cs * vel);
-    fr_set_top<R>(f, f.t + sn * vel * (R)-1);
-    if (rob_hit_wall<R>(f, sp)) { fr_set_cx<R>(f, px); fr_set_cy<R>(f, py); }
-    rob_clamp<R>(f, sp);
-}
-template <typename R> RR_HD void rob_move_angular(FR<R> &f, const SimParams<R> &sp, R w, bool has_c, V2<R> c, R adj) {
-    R rot_prior = f.rot, px = f.cx, py = f.cy;
-    fr_set_rot<R>(f, f.rot + w, sp.rob_cdist);
-    if (has_c) {
-        R sn, cs;
-        m_sincos(radians<R>(f.rot + adj), sn, cs);
-        fr_set_cx<R>(f, c.x + (R)16 * cs);
-        fr_set_cy<R>(f, c.y - (R)16 * sn);
-    }
-    if (rob_hit_wall<R>(f, sp)) {
-        fr_set_cx<R>(f, px); fr_set_cy<R>(f, py);
-        fr_set_rot<R>(f, rot_prior, sp.rob_cdist);
-    }
-    rob_clamp<R>(f, sp);
-}
 // Robot.move (RR_Robot.py:106-108,139-234).  Lanes of one wavefront drive robots with different thrust patterns; the
 // three trig evaluations a move can need (heading or pivot direction, the rotation setter's 360-rot, the re-centring
 // angle) are independent of each other, so they are issued up front as straight-line code -- one latency instead
 // of three serialised divergent paths -- and the cheap bookkeeping then selects what its move type uses.  Every
-// value is computed from the same operands in the same order as rob_move_linear / rob_move_angular above.
+// value is computed from the same operands in the same order as Robot._move_linear / _move_angular
+// (RR_Robot.py:181-234): wall test on the incrementally kept edges, revert of centre (and rotation), 0.5 clamp.
 template <class C> RR_HD void robot_move_lane(Arena<C> &A, const SimParams<typename C::Real> &sp, int r) {
     using R = typename C::Real;
     const int L = A.i.thl[r], Rt = A.i.thr[r];
@@ -938,12 +911,6 @@ template <class C> RR_HDN void resolve_bot_collisions(Arena<C> &A, const SimPara
         }
         pairs = detect_robot_pairs(A);
     }
-}
-template <class C> RR_HD void refresh_inner(Arena<C> &A, const SimParams<typename C::Real> &sp) {
-    RR_FOR_LANES(l) {
-        if (l < C::NR) refresh_inner_lane(A, sp, l);
-    }
-    RR_SYNC();
 }
 template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t bots_moved, int &st) {
     bool naughty = true;
