@@ -235,3 +235,48 @@ def test_reset_on_fault_replaces_faulted_arenas():
     for _ in range(4):
         _, _, d3, i3 = env.step(a)
     assert int(((i3.status & 63) != 0).sum()) < max(2, lingering // 4)
+
+
+@pytest.mark.parametrize("preset,n", [("T", 1), ("T", 33), ("T", 1001), ("G", 1), ("G", 7), ("G", 9), ("G", 1001)])
+def test_ragged_batch_sizes_match_oracle(preset, n):
+    """Batch sizes that leave the last wavefront partly empty (several arenas share a wavefront): every arena still
+    matches the oracle and nothing outside the batch is touched."""
+    rr = _rr()
+    env = rr.BatchedRoboRugbyEnv(n, preset=preset, seed=21, time_limit=False, auto_reset=False)
+    env.reset()
+    na = env.preset.nr
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(n)
+    for _ in range(3):
+        pre = {k: v.cpu().numpy() for k, v in env.get_state().items()}
+        acts = torch.randint(0, 8, (n, na), generator=gen, device="cuda", dtype=torch.int32)
+        o, r, d, info = env.step_f64(acts)
+        post = {k: v.cpu().numpy() for k, v in env.get_state().items()}
+        for a in sorted(set([0, n - 1, n // 2] + list(range(0, n, 97)))):
+            orc = ol.OracleEnv(preset)
+            orc.set_state(pre["robots"][a], pre["robots_i"][a], pre["balls"][a], None, pre["step"][a])
+            res = orc.step(acts[a].cpu().numpy())
+            if res["status"] & 63:
+                continue
+            os_ = orc.get_state()
+            assert np.allclose(os_["balls"], post["balls"][a], atol=1e-9, rtol=0)
+            assert np.allclose(os_["robots"][:, :7], post["robots"][a][:, :7], atol=1e-9, rtol=0)
+            assert np.allclose(res["obs"], o[a].cpu().numpy(), atol=1e-9, rtol=0)
+
+
+def test_abi_rejects_misuse_without_crashing():
+    rr = _rr()
+    from roborugby_amd._lib import RRError
+    env = rr.BatchedRoboRugbyEnv(8, preset="T")
+    with pytest.raises(Exception, match="commands but only 1 robots"):
+        env.step(torch.zeros(8, 2, dtype=torch.int32, device="cuda"))
+    with pytest.raises(RRError, match="bad team/robot/ball index"):
+        env.get_game_state(int_team=1, robot_idx=3)
+    import dataclasses
+    with pytest.raises(RRError, match="unsupported entity counts"):
+        rr.BatchedRoboRugbyEnv(8, preset=dataclasses.replace(rr.PRESETS["T"], nb_pos=2))
+    with pytest.raises(RRError, match="num_envs must be positive"):
+        rr.BatchedRoboRugbyEnv(0, preset="T")
+    # bad actions are a per-arena status, not an error: the arena keeps its previous thrust (KeyError in the reference)
+    obs, rew, done, info = env.step(torch.full((8,), 9, dtype=torch.int32, device="cuda"))
+    assert bool(((info.status & 128) != 0).all())
