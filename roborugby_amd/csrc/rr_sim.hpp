@@ -87,6 +87,18 @@ __device__ unsigned long long g_rr_prof[32];
 #define RR_STAMP(id) do { } while (0)
 #endif
 
+// host emulation only: print the response branches taken (tests bisect mismatches against the oracle with it)
+#if !RR_GPU && defined(RR_EMU_TRACE)
+#include <stdio.h>
+#define RR_TRACE(...) do { if (RR_EMU_TRACE) fprintf(stderr, __VA_ARGS__); } while (0)
+#else
+#define RR_TRACE(...) do { } while (0)
+#endif
+
+#ifndef RR_NUM_SUBSTEPS
+#define RR_NUM_SUBSTEPS 12 // MOVES_PER_FRAME (RR_Constants.py:13); only the emulation harness overrides it to bisect
+#endif
+
 namespace rr {
 
 #if RR_GPU
@@ -709,6 +721,7 @@ template <class C> RR_HDN void apply_force_to_ball(Arena<C> &A, const SimParams<
     const int k = first_surface_hit(A, r, dia, cbuf);
     if (k >= 0) {
         const int sd = k >> 1, d = k & 1;
+        RR_TRACE("E force surface s=%d d=%d b=%d r=%d\n", sd, d, b, r);
         Seg<R> side = robot_side(A, r, sd);
         V2<R> I = line_intersection<R>(side, dia[d], st);
         R da = dist<R>(dia[d].a, rc), db = dist<R>(dia[d].b, rc);
@@ -719,6 +732,7 @@ template <class C> RR_HDN void apply_force_to_ball(Arena<C> &A, const SimParams<
     } else {
         const int c = first_corner_hit(A, r, bc, (R)7 + cbuf);
         if (c >= 0) {
+            RR_TRACE("E force corner c=%d b=%d r=%d\n", c, b, r);
             R px, py, prel[8];
             robot_prev_frame(A, sp, r, bots_moved, px, py, prel);
             V2<R> bcn = robot_corner(A, r, c);
@@ -763,12 +777,14 @@ template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, const SimParams<
         robot_prev_frame(A, sp, r, bots_moved, px, py, prel);
         if (k >= 0) {
             const int sd = k >> 1, d = k & 1;
+            RR_TRACE("E bounce surface s=%d d=%d b=%d r=%d v=(%.17g,%.17g)\n", sd, d, b, r, (double)vx, (double)vy);
             Seg<R> side = robot_side(A, r, sd);
             const int ca = side_a(sd), cb = side_b(sd);
             Seg<R> sprev = { { px + prel[2 * ca], py + prel[2 * ca + 1] }, { px + prel[2 * cb], py + prel[2 * cb + 1] } };
             V2<R> I = line_intersection<R>(side, dia[d], st);
             V2<R> Ip = line_intersection<R>(sprev, dia[d], st);
             R da = dist<R>(dia[d].a, Ip), db = dist<R>(dia[d].b, Ip);
+            RR_TRACE("E   I=(%.17g,%.17g) Ip=(%.17g,%.17g) da=%.17g db=%.17g prev=(%.17g,%.17g)\n", (double)I.x, (double)I.y, (double)Ip.x, (double)Ip.y, (double)da, (double)db, (double)px, (double)py);
             V2<R> cp = (da < db) ? dia[d].a : dia[d].b, opp = (da >= db) ? dia[d].a : dia[d].b;
             V2<R> con = { opp.x - cp.x, opp.y - cp.y };
             R d2;
@@ -777,6 +793,7 @@ template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, const SimParams<
             mvx = (I.x - cp.x) + con.x * cbuf / sq;
             mvy = (I.y - cp.y) + con.y * cbuf / sq;
         } else {
+            RR_TRACE("E bounce corner c=%d b=%d r=%d v=(%.17g,%.17g)\n", c, b, r, (double)vx, (double)vy);
             V2<R> bcn = robot_corner(A, r, c);
             V2<R> pc = { px + prel[2 * c], py + prel[2 * c + 1] };
             V2<R> con = { bc.x - (bcn.x * (R)3 + pc.x) / (R)4, bc.y - (bcn.y * (R)3 + pc.y) / (R)4 };
@@ -925,6 +942,7 @@ template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimPar
             if (!(bb & (1ull << p))) continue;
             int i, j;
             pair_of<C>(p, C::NB, i, j);
+            RR_TRACE("E pass %d bb %d %d\n", count, i, j);
             naughty = true;
             bounce_balls(A, i, j, st);
         }
@@ -1006,6 +1024,7 @@ template <class C>
 RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &naughty, int &st, uint32_t &prev_moved) {
     using R = typename C::Real;
     uint32_t bots_moved = (1u << C::NR) - 1, balls_moved = (1u << C::NB) - 1;
+    RR_TRACE("E substep\n");
     RR_T0();
     RR_FOR_LANES(l) {
         if (l < C::NR) {
@@ -1047,6 +1066,7 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     RR_STAMP(2);
     if (m_br) { // _push_balls (RR_EnvBase.py:335-339): frozen hit list, ball-major order
         uint32_t br = detect_ball_robot(A, sp);
+        RR_TRACE("E push mask %08x\n", br);
 #pragma unroll 1
         for (int p = 0; p < C::NB * C::NR; p++) {
             if (!(br & (1u << p))) continue;
@@ -1400,7 +1420,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     RR_STAMP(8);
     uint32_t prev_moved = 0;
 #pragma unroll 1
-    for (int f = 0; f < 12; f++) substep(A, sp, naughty, st, prev_moved); // MOVES_PER_FRAME
+    for (int f = 0; f < RR_NUM_SUBSTEPS; f++) substep(A, sp, naughty, st, prev_moved); // MOVES_PER_FRAME
     substeps_end(A, prev_moved);
     RR_STAMP(9);
     // ---- on_step_end: NaughtyBots, ChasePosBall, PushPosBallsToGoal (SURVEY 3.1 accumulation order)

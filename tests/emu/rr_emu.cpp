@@ -2,6 +2,10 @@
 // "lane-parallel" phase is a 64-iteration loop.  TEST HARNESS ONLY: it lets the CPU test-suite
 // check the kernel's phase logic (lane->task maps, ballot masks, response ordering) against the
 // oracle without a GPU.  The product library never links or loads this.
+static int g_dbg_substeps = 12;
+static int g_dbg_trace = 0;
+#define RR_NUM_SUBSTEPS g_dbg_substeps
+#define RR_EMU_TRACE g_dbg_trace
 #include "../../roborugby_amd/csrc/rr_sim.hpp"
 #include <cmath>
 #include <cstdlib>
@@ -83,6 +87,8 @@ struct Handle { int kind; void *p; };
     }
 
 extern "C" {
+void emu_debug_set_substeps(int k) { g_dbg_substeps = k; }
+void emu_debug_trace(int on) { g_dbg_trace = on; }
 // preset: 0 = T, 1 = G ; f32: 0/1 ; f32 == 2 selects the narrow-virtual-wave fp64 build
 Handle *emu_create(int preset, int f32, double W, double H, int game_len, int game_mode, int time_limit, int auto_reset,
                    uint64_t seed) {
