@@ -282,6 +282,7 @@ template <class C> struct Arena {
     R psx[NR], psy[NR]; // robot centre at step begin (rectDblPriorStep)
     R bfx[NB], bfy[NB], pfx[NB], pfy[NB];
     int32_t bmass[NB];
+    int32_t bbm[NB], brc[NB]; // per-ball hit / close bit masks of the contact sweeps (one lane per ball writes its own)
     int32_t sides_ok; // sm/sc match the current robot poses (rebuilt lazily by the first phase that needs them)
     union { // the lidar candidates are only alive inside observe(), the inner-square offsets only inside a sub-step
         R irel[NR][8];                    // corner offsets of the ball's inner square at rot+45 (diameter end points)
@@ -546,23 +547,25 @@ template <class C> RR_HD uint32_t detect_robot_pairs(Arena<C> &A) {
 // corners against the radius and its diameter against the four sides.  Bit (b*NR + r) of the result.
 template <class C> RR_HD uint32_t detect_ball_robot(Arena<C> &A, const SimParams<typename C::Real> &sp) {
     using R = typename C::Real;
-    constexpr int NP = C::NB * C::NR;
-    // broad phase: one lane per (ball, robot) pair
-    uint32_t close = 0;
-    for (int base = 0; base < NP; base += C::VW) {
-        uint64_t cm = 0;
-        RR_FOR_LANES(l) {
-            bool c = false;
-            int t = base + l;
-            if (t < NP) {
-                int r = t % C::NR, b = t / C::NR;
-                R dx = A.p.bcx[b] - A.p.rcx[r], dy = A.p.bcy[b] - A.p.rcy[r];
-                c = dx * dx + dy * dy <= cull_br2<R>();
+    // broad phase: one lane per ball sweeps the robots and publishes its NR-bit mask
+    uint64_t anyc = 0;
+    RR_FOR_LANES(l) {
+        bool c = false;
+        if (l < C::NB) {
+            int msk = 0;
+            for (int r = 0; r < C::NR; r++) {
+                R dx = A.p.bcx[l] - A.p.rcx[r], dy = A.p.bcy[l] - A.p.rcy[r];
+                msk |= (dx * dx + dy * dy <= cull_br2<R>()) ? (1 << r) : 0;
             }
-            RR_VOTE(cm, l, c);
+            A.brc[l] = msk;
+            c = msk != 0;
         }
-        close |= (uint32_t)(cm << base);
+        RR_VOTE(anyc, l, c);
     }
+    if (!anyc) return 0;
+    RR_SYNC();
+    uint32_t close = 0;
+    for (int b = 0; b < C::NB; b++) close |= (uint32_t)A.brc[b] << (b * C::NR);
     if (!close) return 0;
     // narrow phase: the inner-square corner offsets (rot+45) are only needed now
     RR_FOR_LANES(l) {
@@ -571,7 +574,7 @@ template <class C> RR_HD uint32_t detect_ball_robot(Arena<C> &A, const SimParams
     RR_SYNC();
     ensure_sides(A);
     uint32_t pairs = 0;
-    constexpr int NT = NP * 2; // task = (pair, diameter)
+    constexpr int NT = C::NB * C::NR * 2; // task = (pair, diameter)
     for (int base = 0; base < NT; base += C::VW) {
         constexpr uint32_t ALL = (C::VW >= 64) ? 0xFFFFFFFFu : ((1u << (C::VW / 2)) - 1u);
         if (!((close >> (base >> 1)) & ALL)) continue;
@@ -603,26 +606,33 @@ template <class C> RR_HD uint32_t detect_ball_robot(Arena<C> &A, const SimParams
     return pairs;
 }
 // balls_collided (RR_TrashyPhysics.py:72-73): one lane per ball pair
-template <class C> RR_HD uint64_t detect_ball_pairs(const Arena<C> &A) {
+template <class C> RR_HD uint64_t detect_ball_pairs(Arena<C> &A) {
     using R = typename C::Real;
-    uint64_t mask = 0;
     if (C::NPB == 0) return 0;
-    for (int base = 0; base < C::NPB; base += C::VW) {
-        uint64_t m = 0;
-        RR_FOR_LANES(l) {
-            bool hit = false;
-            int t = base + l;
-            if (t < C::NPB) {
-                int i, j;
-                pair_of<C>(t, C::NB, i, j);
-                V2<R> a = { A.p.bcx[i], A.p.bcy[i] }, b = { A.p.bcx[j], A.p.bcy[j] };
+    // one lane per ball i tests the later balls j > i; the reference's sqrt test only when d^2 <= 197 (14^2 + slack)
+    uint64_t anyh = 0;
+    RR_FOR_LANES(l) {
+        bool h = false;
+        if (l < C::NB) {
+            int msk = 0;
+            for (int j = 0; j < C::NB; j++) {
+                V2<R> a = { A.p.bcx[l], A.p.bcy[l] }, b = { A.p.bcx[j], A.p.bcy[j] };
                 R dx = b.x - a.x, dy = b.y - a.y;
-                // sqrt(x) <= 14 needs x <= 196 (+ulps): only then is the reference's own test evaluated
-                if (dx * dx + dy * dy <= (R)197) hit = dist<R>(a, b) <= (R)14;
+                if (j > l && dx * dx + dy * dy <= (R)197) msk |= (dist<R>(a, b) <= (R)14) ? (1 << j) : 0;
             }
-            RR_VOTE(m, l, hit);
+            A.bbm[l] = msk;
+            h = msk != 0;
         }
-        mask |= m << base;
+        RR_VOTE(anyh, l, h);
+    }
+    if (!anyh) return 0;
+    RR_SYNC();
+    uint64_t mask = 0; // bit p of the nested-loop pair order (i < j)
+    int p = 0;
+    for (int i = 0; i < C::NB; i++) {
+        const int mi = A.bbm[i];
+        for (int j = i + 1; j < C::NB; j++, p++)
+            if ((mi >> j) & 1) mask |= 1ull << p;
     }
     return mask;
 }
@@ -668,6 +678,7 @@ template <class C> RR_HD void force_diameters(const Arena<C> &A, int r, V2<typen
 template <class C>
 RR_HD int first_surface_hit(Arena<C> &A, int r, const Seg<typename C::Real> dia[2], typename C::Real buf) {
     using R = typename C::Real;
+    ensure_sides(A);
     uint32_t hits = 0;
     for (int base = 0; base < 8; base += C::VW) {
         uint64_t m = 0;
@@ -678,7 +689,9 @@ RR_HD int first_surface_hit(Arena<C> &A, int r, const Seg<typename C::Real> dia[
                 const int sd = t >> 1, d = t & 1;
                 int st = 0;
                 Seg<R> side = robot_side(A, r, sd);
-                V2<R> I = line_intersection<R>(side, dia[d], st);
+                R md, cd;
+                slope_yint<R>(dia[d].a, dia[d].b, md, cd, st);
+                V2<R> I = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, md, cd, dia[d].a.x); // cached side slope
                 hit = within<R>(I, side, (R)0) & within<R>(I, dia[d], buf);
             }
             RR_VOTE(m, l, hit);
@@ -723,7 +736,9 @@ template <class C> RR_HDN void apply_force_to_ball(Arena<C> &A, const SimParams<
         const int sd = k >> 1, d = k & 1;
         RR_TRACE("E force surface s=%d d=%d b=%d r=%d\n", sd, d, b, r);
         Seg<R> side = robot_side(A, r, sd);
-        V2<R> I = line_intersection<R>(side, dia[d], st);
+        R md, cd;
+        slope_yint<R>(dia[d].a, dia[d].b, md, cd, st);
+        V2<R> I = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, md, cd, dia[d].a.x);
         R da = dist<R>(dia[d].a, rc), db = dist<R>(dia[d].b, rc);
         V2<R> cp = (da < db) ? dia[d].a : dia[d].b, opp = (da >= db) ? dia[d].a : dia[d].b;
         fx += (I.x - cp.x) + (opp.x - cp.x) * cbuf / (R)14;
@@ -781,8 +796,11 @@ template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, const SimParams<
             Seg<R> side = robot_side(A, r, sd);
             const int ca = side_a(sd), cb = side_b(sd);
             Seg<R> sprev = { { px + prel[2 * ca], py + prel[2 * ca + 1] }, { px + prel[2 * cb], py + prel[2 * cb + 1] } };
-            V2<R> I = line_intersection<R>(side, dia[d], st);
-            V2<R> Ip = line_intersection<R>(sprev, dia[d], st);
+            R md, cd, mp, cpv;
+            slope_yint<R>(dia[d].a, dia[d].b, md, cd, st);
+            slope_yint<R>(sprev.a, sprev.b, mp, cpv, st);
+            V2<R> I = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, md, cd, dia[d].a.x);
+            V2<R> Ip = intersect_mb<R>(mp, cpv, sprev.a.x, md, cd, dia[d].a.x);
             R da = dist<R>(dia[d].a, Ip), db = dist<R>(dia[d].b, Ip);
             RR_TRACE("E   I=(%.17g,%.17g) Ip=(%.17g,%.17g) da=%.17g db=%.17g prev=(%.17g,%.17g)\n", (double)I.x, (double)I.y, (double)Ip.x, (double)Ip.y, (double)da, (double)db, (double)px, (double)py);
             V2<R> cp = (da < db) ? dia[d].a : dia[d].b, opp = (da >= db) ? dia[d].a : dia[d].b;

@@ -13,14 +13,24 @@ lib = _lib.load()
 buf = (C.c_ulonglong * 32)()
 na = env.preset.nr
 g = torch.Generator(device='cuda'); g.manual_seed(1)
+last = [env.get_game_state()]
 def act():
-    return torch.randint(0, 8, (n, na), generator=g, device='cuda', dtype=torch.int32) if mode == "random" else torch.full((n, na), 8, device='cuda', dtype=torch.int32)
-for _ in range(5): env.step(act())
+    if mode == "random":
+        return torch.randint(0, 8, (n, na), generator=g, device='cuda', dtype=torch.int32)
+    if mode == "chase":
+        o = last[0]
+        d = (o[:, 1] - o[:, 0] + 540.0) % 360.0 - 180.0
+        a0 = torch.where(d.abs() < 8, 0, torch.where(d > 0, 2, 3)).to(torch.int32).view(n, 1)
+        return torch.cat([a0, torch.randint(0, 8, (n, na - 1), generator=g, device='cuda', dtype=torch.int32)], 1) if na > 1 else a0
+    return torch.full((n, na), 8, device='cuda', dtype=torch.int32)
+def step():
+    last[0] = env.step(act())[0]
+for _ in range(150 if mode == "chase" else 5): step()
 torch.cuda.synchronize(); lib.rr_debug_phase_cycles(buf, 1)
 K = 20
-for _ in range(K): env.step(act())
+for _ in range(K): step()
 torch.cuda.synchronize(); lib.rr_debug_phase_cycles(buf, 0)
-names = ["frame_begin", "move_bots", "K1 robot pairs", "push (br detect+resp)", "roll", "resolve loop", "undo", "frame_end",
+names = ["(unused)", "frame hooks + move_bots", "rr+br broad phase, K1", "push (br detect+resp)", "roll", "resolve loop", "undo", "(unused)",
          "step_begin", "(12 substeps total)", "rewards", "obs+out", "load+derive", "store"]
 v = list(buf)[:14]
 tot = sum(v[i] for i in (8, 9, 10, 11, 12, 13))
