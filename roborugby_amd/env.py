@@ -66,7 +66,7 @@ class BatchedRoboRugbyEnv:
     reward_range = (-float("inf"), float("inf"))
 
     def __init__(self, num_envs, preset="T", device=None, seed=0, time_limit=True, auto_reset=True, dtype="f64",
-                 arena_offset=0, env_id="RoboRugbySimpleDuel-v3", reset_on_fault=None):
+                 arena_offset=0, env_id="RoboRugbySimpleDuel-v3", reset_on_fault=None, action_mode="discrete"):
         self.preset = PRESETS[preset] if isinstance(preset, str) else preset
         assert isinstance(self.preset, Preset)
         if not torch.cuda.is_available():
@@ -95,7 +95,12 @@ class BatchedRoboRugbyEnv:
         self._h = h
         m = max(p.arena_w, p.arena_h, 360)  # RR_Observers.py:30-37
         self.observation_space = Box(-m, m, (11,), np.float32)
-        self.action_space = Discrete(8)  # RR_EnvBase.py:610
+        # GameEnv_Simple: Discrete(8) (RR_EnvBase.py:610); bare GameEnv: Box(-1, 1, (2*happy robots,)) (RR_EnvBase.py:118-123),
+        # the surface Training_SAC_pytorch.py:270,423 reads (`action_space.high`, `.shape[0]`)
+        if action_mode not in ("discrete", "thrust"):
+            raise ValueError("action_mode must be 'discrete' or 'thrust'")
+        self.action_mode = action_mode
+        self.action_space = Discrete(8) if action_mode == "discrete" else Box(-1.0, 1.0, (2 * p.nr_happy,), np.float32)
         self.spec = types.SimpleNamespace(id=env_id, max_episode_steps=p.game_len_steps, nondeterministic=True,
                                           reward_threshold=1.0)  # robo_rugby/__init__.py:28-34
         self.has_grumpy = p.nr_grumpy > 0
@@ -129,6 +134,8 @@ class BatchedRoboRugbyEnv:
         (obs, reward, done_u8, obs_g, reward_g, status) tensors to reuse."""
         N = self.num_envs
         a = torch.as_tensor(actions, device=self.device)
+        if self.action_mode == "thrust" or a.is_floating_point():
+            return self.step_thrust(a)
         if a.dim() == 1:
             a = a.view(N, 1)
         if a.shape[0] != N or a.dim() != 2:
@@ -185,9 +192,17 @@ class BatchedRoboRugbyEnv:
         _lib.check(fn(self._h, team, int(robot_idx), int(ball_idx), _ptr(obs), self._stream()), "rr_observe")
         return obs
 
-    def render(self, mode="human"):
-        """Rendering (RR_EnvBase.py:218-258) is pygame UI and out of scope; kept so callers' render() is harmless."""
-        return None
+    def render(self, mode="human", arena=0):
+        """The pygame window (RR_EnvBase.py:218-258) is UI and out of scope: 'human' is a no-op so callers' render()
+        stays harmless; 'rgb_array' returns a CPU debug picture of ONE arena (arena width + 300-px dashboard strip like
+        the reference's surface) drawn with PIL from the device state."""
+        if mode == "human":
+            return None
+        if mode != "rgb_array":
+            raise NotImplementedError("Other mode types not supported.")
+        from .render import draw_arena
+        st = self.get_state()
+        return draw_arena(self.preset, st["robots"][arena].cpu().numpy(), st["balls"][arena].cpu().numpy())
 
     def seed(self, seed=None):
         """Like the reference (RR_EnvBase.py:568-570) this does not re-seed placement; the reset RNG is keyed at
@@ -263,9 +278,9 @@ class RoboRugbyEnv:
     metadata = BatchedRoboRugbyEnv.metadata
     reward_range = BatchedRoboRugbyEnv.reward_range
 
-    def __init__(self, preset="T", device=None, seed=0, time_limit=True, dtype="f64"):
+    def __init__(self, preset="T", device=None, seed=0, time_limit=True, dtype="f64", action_mode="discrete"):
         self._b = BatchedRoboRugbyEnv(1, preset=preset, device=device, seed=seed, time_limit=time_limit,
-                                      auto_reset=False, dtype=dtype)
+                                      auto_reset=False, dtype=dtype, action_mode=action_mode)
         self.observation_space = self._b.observation_space
         self.action_space = self._b.action_space
         self.spec = self._b.spec
@@ -280,10 +295,14 @@ class RoboRugbyEnv:
 
     def step(self, lstArgs):
         arr = np.concatenate([np.asarray(a).reshape(-1) for a in lstArgs], axis=None) if len(lstArgs) else np.zeros(0)
-        if len(arr) > self.preset.nr:
-            raise Exception(f"{len(arr)} commands but only {self.preset.nr} robots.")
-        a = torch.as_tensor(arr.astype(np.int64)).view(1, -1)
-        obs, rew, done, info = self._b.step(a)
+        if self._b.action_mode == "thrust":  # GameEnv.step: flat (L, R) thrust pairs (RR_EnvBase.py:269-273)
+            if len(arr) > self.preset.nr * 2:
+                raise Exception(f"{len(arr)} commands but only {self.preset.nr * 2} robot engines.")
+            obs, rew, done, info = self._b.step_thrust(torch.as_tensor(arr.astype(np.float32)).view(1, -1))
+        else:
+            if len(arr) > self.preset.nr:
+                raise Exception(f"{len(arr)} commands but only {self.preset.nr} robots.")
+            obs, rew, done, info = self._b.step(torch.as_tensor(arr.astype(np.int64)).view(1, -1))
         st = int(info.status[0])
         for bit, msg in STATUS_BITS.items():
             if st & bit:
@@ -298,7 +317,7 @@ class RoboRugbyEnv:
         return None if o is None else o[0].double().cpu().numpy()
 
     def render(self, mode="human"):
-        return None
+        return self._b.render(mode)
 
     def seed(self, seed=None):
         return [seed]
