@@ -160,7 +160,7 @@ def main():
     total_steps = rrd.reduce_sum(float(local_steps), dev)
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / K
     kern_ms = rrd.reduce_max(kern_ms, dev)
-    status_bits = int(torch.bitwise_and(out[5], ~1024 & ~256).max().item())
+    status_bits = int(torch.bitwise_and(out[5], 0xFFFF & ~1024 & ~256).max().item())
 
     if rank == 0:
         bytes_per_step = p.algorithmic_bytes_per_step(na)            # G 601 B, T 149 B

@@ -37,6 +37,8 @@ extern "C" {
 #define RR_STATUS_UNDO_WARN 256        /* RR_EnvBase.py:419  GAME_MODE warning, step continued        */
 #define RR_STATUS_RESET_GAVE_UP 512    /* spawn rejection sampling hit its attempt cap                */
 #define RR_STATUS_WAS_RESET 1024       /* this call reset the arena instead of stepping it            */
+#define RR_STATUS_FLAG_MASK 0xFFFF     /* bits 0-15 are the flags above ...                            */
+#define RR_STATUS_NAUGHTY_SHIFT 16     /* ... bits 16+r: robot r joined NaughtyBots' set this step (RR_ScoreKeepers.py:123-128) */
 
 #define RR_DTYPE_F64 0 /* state + arithmetic in fp64: the parity mode (the reference is fp64)         */
 #define RR_DTYPE_F32 1 /* state + arithmetic in fp32: the fast mode                                   */
@@ -112,6 +114,21 @@ int rr_get_state(rr_env *env, double *robots, int32_t *robots_i, double *balls, 
 /* Poses only -- the reference's lst_starting_config format (RR_EnvBase.py:35-52,131-153) plus ball
  * velocities: robots_xyr [N,NR,3], balls_xyv [N,NB,4]; edges re-derived, history cleared. */
 int rr_set_poses(rr_env *env, const double *robots_xyr, const double *balls_xyv, void *stream);
+
+/* ---- the reference's other mixins; SimpleDuel3's own stack is the default and is fused
+ * into the step kernel, anything else is evaluated by light side kernels around it.
+ * Reward keepers, given in on_step_end EXECUTION order (each keeper calls super() first, except NaughtyBots which
+ * never does, so keepers behind it in the MRO do not run): 1 NaughtyBots, 2 ChasePosBall, 3 PushPosBallsToGoal,
+ * 4 DontDriveInGoals, 5 KeepMovingGuys, 6 BaseDestruction, 7 PushNegBallsFromGoal (RR_ScoreKeepers.py:46-179).
+ * Default {1,2,3}.  n <= 8. */
+int rr_set_reward_program(rr_env *env, const int32_t *keeper_ids, int32_t n);
+/* Observers: kind 0 SingleBall_6wayLidar_v2 (11 values), 1 SingleBall_6wayLidar (11, RR_Observers.py:168-285),
+ * 2 PosBall_BasicLidar (5, :116-166), 3 AllCoords (3*NR + 2*NB, :47-83).  obs [N, out_dim]; rows are NaN where the
+ * reference returns None.  out_dim must equal the kind's size. */
+int rr_observe_kind(rr_env *env, int32_t kind, int32_t team, int32_t robot_idx, int32_t ball_idx, float *obs,
+                    int32_t out_dim, void *stream);
+int rr_observe_kind_f64(rr_env *env, int32_t kind, int32_t team, int32_t robot_idx, int32_t ball_idx, double *obs,
+                        int32_t out_dim, void *stream);
 
 /* Logging: return/length of the last finished episode and the number of finished episodes per arena
  * (the caller accumulates `score` the same way, Training_DQN_pytorch.py:345-346). */

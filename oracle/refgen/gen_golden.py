@@ -417,6 +417,146 @@ def gen_reset(R, preset, n=1000):
                         meta=np.array(json.dumps(dict(META, preset=preset, seeds="random.seed(1000+k) before reset()"))))
 
 
+# ------------------------------------------------------------------ other mixins
+KEEPER_IDS = {"NaughtyBots": 1, "ChasePosBall": 2, "PushPosBallsToGoal": 3, "DontDriveInGoals": 4, "KeepMovingGuys": 5,
+              "BaseDestruction": 6, "PushNegBallsFromGoal": 7}
+
+
+def exec_order(mro_names):
+    """on_step_end execution order of a keeper MRO: every keeper calls super() first, except NaughtyBots which
+    does not call it at all (RR_ScoreKeepers.py:130-135), so keepers after it in the MRO never run."""
+    names = list(mro_names)
+    if "NaughtyBots" in names:
+        names = names[:names.index("NaughtyBots") + 1]
+    return [KEEPER_IDS[n] for n in reversed(names)]
+
+
+def alt_observations(R, env):
+    """The other observer mixins evaluated on the same env state through their unbound methods (their helper
+    methods are bound to the env for the duration of the call)."""
+    import types
+    O, c = R.obs, R.const
+
+    def call(cls, **kw):
+        added = []
+        for name in ("_robot_state", "_ball_state"):
+            if hasattr(cls, name) and name not in env.__dict__:
+                setattr(env, name, types.MethodType(getattr(cls, name), env))
+                added.append(name)
+        try:
+            return cls.get_game_state(env, **kw)
+        finally:
+            for name in added:
+                delattr(env, name)
+    out = {}
+    for tag, team in (("h", c.TEAM_HAPPY), ("g", c.TEAM_GRUMPY)):
+        has = (len(env.lstHappyBots) if team == c.TEAM_HAPPY else len(env.lstGrumpyBots)) > 0
+        v1 = call(O.SingleBall_6wayLidar, int_team=team) if has else None
+        bas = call(O.PosBall_BasicLidar, int_team=team) if has else None
+        out["v1_" + tag] = np.full(11, NAN) if v1 is None else np.asarray(v1, dtype=np.float64)
+        out["basic_" + tag] = np.full(5, NAN) if bas is None else np.asarray(bas, dtype=np.float64)
+        out["all_" + tag] = np.asarray(call(O.AllCoords, int_team=team), dtype=np.float64)
+    last = env.lstRobots[-1]
+    out["basic_last"] = np.asarray(call(O.PosBall_BasicLidar, obj_robot=last), dtype=np.float64)
+    out["v1_last_negball"] = np.asarray(call(O.SingleBall_6wayLidar, obj_robot=last, obj_ball=env.lstBalls[-1]), dtype=np.float64)
+    return out
+
+
+def gen_mix(R, preset):
+    sk, O, base, c = R.sk, R.obs, R.base, R.const
+    cnt = Counters(R)  # also turns the reference's endless GAME_MODE warning loop into an exception
+    R.envs.SimpleDuel3()  # first constructed env fixes the shared class-level observation_space (Obs:30-37)
+
+    class MixA(sk.DontDriveInGoals, sk.KeepMovingGuys, sk.PushNegBallsFromGoal, sk.BaseDestruction,
+               sk.PushPosBallsToGoal, sk.ChasePosBall, O.SingleBall_6wayLidar, base.GameEnv_Simple):
+        pass
+
+    class MixB(sk.KeepMovingGuys, sk.NaughtyBots, sk.DontDriveInGoals, O.SingleBall_6wayLidar_v2, base.GameEnv_Simple):
+        pass
+
+    progs = {"A": ["DontDriveInGoals", "KeepMovingGuys", "PushNegBallsFromGoal", "BaseDestruction", "PushPosBallsToGoal",
+                   "ChasePosBall"],
+             "B": ["KeepMovingGuys", "NaughtyBots", "DontDriveInGoals"]}
+    rng = random.Random(4242 if preset == "G" else 4343)
+    W, H = c.ARENA_WIDTH, c.ARENA_HEIGHT
+    eps = []
+    for which, cls in (("A", MixA), ("B", MixB)):
+        env = cls()
+        NR, NB = len(env.lstRobots), len(env.lstBalls)
+        for e in range(4 if preset == "G" else 5):
+            random.seed(rng.randint(0, 1 << 30))
+            env.reset()
+            # lure the chasers into the goal corners: park the balls inside the goal triangles
+            spots = [(W - 70, H - 60), (60, 70), (W - 40, H - 150), (150, 40), (W - 150, H - 40), (40, 150), (W - 100, H - 100), (90, 90)]
+            for i, b in enumerate(env.lstBalls):
+                if e % 2 == 0:
+                    b.rectDbl.center = spots[(i + e) % len(spots)]
+            nsteps = 160 if preset == "G" else 260
+            S = dict(robots=[], robots_i=[], balls=[], inner=[], step=[])
+            rec = {k: [] for k in ("actions", "reward", "reward_g", "done", "v1_h", "v1_g", "basic_h", "basic_g", "all_h", "all_g",
+                                   "basic_last", "v1_last_negball")}
+
+            def put():
+                d = dump_state(env, R)
+                for k in S:
+                    S[k].append(d[k])
+            put()
+            a0 = alt_observations(R, env)
+            length = 0
+            for s in range(nsteps):
+                if s % 40 < 6:
+                    acts = [8 if False else rng.choice([0, 1])] * NR if s % 80 < 3 else [rng.randint(0, 7) for _ in range(NR)]
+                else:
+                    acts = policy_actions(env, R, "chase", rng, NR)
+                if s % 50 == 49 and NR > 1:
+                    acts = acts[:1]  # only robot 0 gets a new action; the others keep their thrust
+                try:
+                    cnt.warns = 0
+                    o, r, d, info = env.step(acts)
+                except Exception:
+                    break
+                rec["actions"].append(list(acts) + [-1] * (NR - len(acts)))
+                rec["reward"].append(r)
+                rec["reward_g"].append(info.dblGrumpyScore)
+                rec["done"].append(d)
+                ao = alt_observations(R, env)
+                for k, v in ao.items():
+                    rec[k].append(v)
+                put()
+                length += 1
+                if d:
+                    break
+            ep = {"state_" + k: np.array(v) for k, v in S.items()}
+            ep.update({k: np.array(v) for k, v in rec.items()})
+            ep["length"] = length
+            ep["which"] = which
+            ep["alt0"] = a0
+            eps.append(ep)
+            print(preset, "mix", which, "len", length, "sum reward", float(np.sum(rec["reward"])), flush=True)
+    smax = max(e["length"] for e in eps)
+    out = {}
+    for k in eps[0]:
+        if k in ("length", "which", "alt0"):
+            continue
+        arrs = []
+        for e in eps:
+            a = np.asarray(e[k])
+            tgt = smax + 1 if k.startswith("state_") else smax
+            padded = np.zeros((tgt,) + a.shape[1:], a.dtype)
+            padded[:a.shape[0]] = a
+            arrs.append(padded)
+        out[k] = np.stack(arrs)
+    out["length"] = np.array([e["length"] for e in eps], np.int32)
+    out["which"] = np.array([0 if e["which"] == "A" else 1 for e in eps], np.int32)
+    for k in eps[0]["alt0"]:
+        out["alt0_" + k] = np.stack([e["alt0"][k] for e in eps])
+    meta = dict(META, preset=preset, programs_mro=progs, programs_exec={k: exec_order(v) for k, v in progs.items()},
+                keeper_ids=KEEPER_IDS, note="which: 0 = MixA, 1 = MixB; alt observations come from the other observer mixins "
+                "called as unbound methods on the same env state")
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(GOLD, f"mix_{preset}.npz"), **out)
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which == "all":
@@ -433,6 +573,8 @@ def main():
         gen_reset(R, which)
     if "traj" in parts:
         gen_traj(R, which)
+    if "mix" in parts:
+        gen_mix(R, which)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,198 @@
+// rr_extras.hpp -- the reference's OTHER reward / observation mixins, kept off the hot kernel.
+//
+// SimpleDuel3's stack (NaughtyBots + ChasePosBall + PushPosBallsToGoal, SingleBall_6wayLidar_v2) is fused into k_step.
+// Any other keeper stack / observer is evaluated by the light thread-per-arena kernels below, straight from the HBM
+// records: k_extras_begin snapshots what on_step_begin captures (rectDblPriorStep copies, ball_dist_sum), k_step runs
+// and publishes the NaughtyBots set in status bits 16.., k_extras_end re-evaluates the whole keeper program in the
+// reference's on_step_end order and overwrites the rewards; k_observe_kind serves the other observers.
+#pragma once
+#include "rr_sim.hpp"
+
+namespace rr {
+
+enum : int { KEEPER_NAUGHTY = 1, KEEPER_CHASE = 2, KEEPER_PUSHPOS = 3, KEEPER_DONTDRIVE = 4, KEEPER_KEEPMOVING = 5,
+             KEEPER_BASEDESTRUCTION = 6, KEEPER_PUSHNEG = 7 };
+enum : int { OBS_V2 = 0, OBS_V1 = 1, OBS_BASIC = 2, OBS_ALLCOORDS = 3 };
+
+struct Program { int32_t n; int32_t id[8]; };
+
+// read-only view of one arena's HBM record (field-major layout of Arena<C>::P)
+template <class C> struct Rec {
+    using R = typename C::Real;
+    const R *p;
+    RR_HD R rcx(int r) const { return p[0 * C::NR + r]; }
+    RR_HD R rcy(int r) const { return p[1 * C::NR + r]; }
+    RR_HD R rrot(int r) const { return p[6 * C::NR + r]; }
+    RR_HD R bcx(int b) const { return p[10 * C::NR + 0 * C::NB + b]; }
+    RR_HD R bcy(int b) const { return p[10 * C::NR + 1 * C::NB + b]; }
+};
+template <class C> RR_HD void rec_corners(const Rec<C> &q, const SimParams<typename C::Real> &sp, int r, V2<typename C::Real> c[4]) {
+    using R = typename C::Real;
+    R rel[8];
+    corners_for<R>(q.rrot(r), (R)10, (R)20, sp.rob_cdist, rel);
+    for (int k = 0; k < 4; k++) c[k] = { q.rcx(r) + rel[2 * k], q.rcy(r) + rel[2 * k + 1] };
+}
+template <typename R> RR_HD Seg<R> side_of(const V2<R> c[4], int s) { Seg<R> g = { c[side_a(s)], c[side_b(s)] }; return g; }
+
+// RightTriangle.contains_point (MyUtils.py:438-445) for the two goal triangles (RR_Goal.py:14-28):
+// happy goal  (W,H),(W,H-240),(W-240,H): hypotenuse origin (W-240, H), vector to (W, H-240)
+// grumpy goal (240,0),(0,240),(0,0)    : hypotenuse origin (240, 0),   vector to (0, 240)
+template <typename R> RR_HD bool goal_contains(bool happy, R W, R H, V2<R> p, int &st) {
+    const R l = happy ? W - (R)240 : (R)0, r = happy ? W : (R)240, t = happy ? H - (R)240 : (R)0, b = happy ? H : (R)240;
+    if (!((l <= p.x && p.x <= r) && (t <= p.y && p.y <= b))) return false;
+    const V2<R> h0 = happy ? V2<R>{ l, b } : V2<R>{ r, t }, h1 = happy ? V2<R>{ r, t } : V2<R>{ l, b };
+    const R sh = div0<R>(h1.y - h0.y, h1.x - h0.x, st), spn = div0<R>(p.y - h0.y, p.x - h0.x, st);
+    return spn >= sh;
+}
+
+// ---- on_step_begin snapshot: [3*NR] rectDblPriorStep copies (cx, cy, rot) + ball_dist_sum
+template <class C> RR_HD void extras_begin(const Rec<C> &q, typename C::Real *xs) {
+    using R = typename C::Real;
+    for (int r = 0; r < C::NR; r++) { // FloatRect.copy(): new rect (0,20,0,40) -> center setter -> rotation setter
+        xs[3 * r + 0] = (R)10 + (q.rcx(r) - (R)10);
+        xs[3 * r + 1] = (R)20 + (q.rcy(r) - (R)20);
+        xs[3 * r + 2] = py_mod<R>(q.rrot(r) + (R)720, (R)360);
+    }
+    R s = (R)0;
+    V2<R> o = { (R)0, (R)0 };
+    for (int b = 0; b < C::NBP; b++) { V2<R> c = { q.bcx(b), q.bcy(b) }; s = s + dist<R>(o, c); }
+    xs[3 * C::NR] = s;
+}
+// ---- on_step_end: the keeper program in execution order
+template <class C, typename O>
+RR_HD void extras_end(const Rec<C> &q, const SimParams<typename C::Real> &sp, const typename C::Real *xs, const Program &pg,
+                      uint32_t naughty, O *reward, O *reward_g, int32_t *status) {
+    using R = typename C::Real;
+    R rh = (R)0, rg = (R)0;
+    int st = 0;
+    for (int k = 0; k < pg.n; k++) {
+        switch (pg.id[k]) {
+        case KEEPER_NAUGHTY:
+            for (int r = 0; r < C::NR; r++) if (naughty & (1u << r)) { if (r < C::NRH) rh -= (R).005; else rg -= (R).005; }
+            break;
+        case KEEPER_CHASE:
+            for (int r = 0; r < C::NR; r++)
+                for (int b = 0; b < C::NBP; b++) {
+                    V2<R> rc = { q.rcx(r), q.rcy(r) }, pc = { xs[3 * r], xs[3 * r + 1] }, bc = { q.bcx(b), q.bcy(b) };
+                    R now = dist<R>(rc, bc), prior = dist<R>(pc, bc);
+                    if (r < C::NRH) rh += (prior - now) * sp.mult_robot; else rg += (prior - now) * sp.mult_robot;
+                }
+            break;
+        case KEEPER_PUSHPOS:
+        case KEEPER_PUSHNEG: { // PushNegBallsFromGoal sums the POSITIVE balls too (reference bug kept), signs flipped
+            R s = (R)0;
+            V2<R> o = { (R)0, (R)0 };
+            for (int b = 0; b < C::NBP; b++) { V2<R> c = { q.bcx(b), q.bcy(b) }; s = s + dist<R>(o, c); }
+            R delta = s - xs[3 * C::NR];
+            if (pg.id[k] == KEEPER_PUSHPOS) { rh += delta * sp.mult_ball; rg -= delta * sp.mult_ball; }
+            else { rh -= delta * sp.mult_ball; rg += delta * sp.mult_ball; }
+        } break;
+        case KEEPER_DONTDRIVE:
+            for (int r = 0; r < C::NR; r++) {
+                V2<R> c[4];
+                rec_corners(q, sp, r, c);
+                bool in = false;
+                for (int g = 0; g < 2 && !in; g++) // happy goal first, then grumpy (RR_ScoreKeepers.py:76-77)
+                    for (int k2 = 0; k2 < 4 && !in; k2++) in = goal_contains<R>(g == 0, sp.W, sp.H, c[k2], st);
+                if (in) { if (r < C::NRH) rh -= (R).005; else rg -= (R).005; }
+            }
+            break;
+        case KEEPER_KEEPMOVING:
+            for (int r = 0; r < C::NR; r++)
+                if (q.rcx(r) == xs[3 * r] && q.rcy(r) == xs[3 * r + 1] && q.rrot(r) == xs[3 * r + 2]) {
+                    if (r < C::NRH) rh -= (R).005; else rg -= (R).005;
+                }
+            break;
+        default: break; // KEEPER_BASEDESTRUCTION: goals are never destroyed on the live path
+        }
+    }
+    *reward = (O)rh;
+    if (reward_g) *reward_g = (O)rg;
+    if (status && st) *status |= st;
+}
+
+// ---- serial two_way_lidar_rect (RR_TrashyPhysics.py:365-391) over the other robots + the walls
+template <class C>
+RR_HD void lidar_serial(const Rec<C> &q, const SimParams<typename C::Real> &sp, int ridx, V2<typename C::Real> a,
+                        V2<typename C::Real> b, typename C::Real &front, typename C::Real &back) {
+    using R = typename C::Real;
+    R f = inf_<R>(), bk = inf_<R>();
+    Seg<R> ray = { a, b };
+    int st = 0;
+    for (int j = 0; j < C::NR; j++) {
+        V2<R> c[4];
+        if (j < C::NR - 1) {
+            rec_corners(q, sp, j < ridx ? j : j + 1, c);
+        } else {
+            const R hx = sp.W / (R)2, hy = sp.H / (R)2; // rect_walls = FloatRect(0, W, 0, H)
+            c[TL] = { hx + -hx, hy + -hy }; c[TR] = { hx + hx, hy + -hy }; c[BL] = { hx + -hx, hy + hy }; c[BR] = { hx + hx, hy + hy };
+        }
+        for (int s = 0; s < 4; s++) {
+            V2<R> I = line_intersection<R>(side_of<R>(c, s), ray, st);
+            R de = dist<R>(I, b), ds = dist<R>(I, a);
+            if (de <= ds && de < f) f = de;
+            if (ds <= de && ds < bk) bk = ds;
+        }
+    }
+    front = f; back = bk;
+}
+// the other observers; returns the number of values written (0 = the reference returns None)
+template <class C, typename O>
+RR_HD int observe_kind(const Rec<C> &q, const SimParams<typename C::Real> &sp, int kind, int team, int ridx, int bidx, O *o) {
+    using R = typename C::Real;
+    int st = 0;
+    if (kind == OBS_ALLCOORDS) { // AllCoords (RR_Observers.py:47-83): own team's robots first
+        int n = 0;
+        const int f0 = team == -1 ? C::NRH : 0, f1 = team == -1 ? C::NR : C::NRH, s0 = team == -1 ? 0 : C::NRH, s1 = team == -1 ? C::NRH : C::NR;
+        for (int r = f0; r < f1; r++) { o[n++] = (O)q.rcx(r); o[n++] = (O)q.rcy(r); o[n++] = (O)q.rrot(r); }
+        for (int r = s0; r < s1; r++) { o[n++] = (O)q.rcx(r); o[n++] = (O)q.rcy(r); o[n++] = (O)q.rrot(r); }
+        for (int b = 0; b < C::NB; b++) { o[n++] = (O)q.bcx(b); o[n++] = (O)q.bcy(b); }
+        return n;
+    }
+    if (ridx < 0) {
+        if (team == 1 && C::NRH == 0) return 0;
+        if (team == -1 && C::NRG == 0) return 0;
+        ridx = team == 1 ? 0 : C::NRH;
+    }
+    V2<R> c[4];
+    rec_corners(q, sp, ridx, c);
+    V2<R> rc = { q.rcx(ridx), q.rcy(ridx) };
+    if (kind == OBS_BASIC) { // PosBall_BasicLidar._robot_state (RR_Observers.py:143-166)
+        V2<R> bc = { q.bcx(0), q.bcy(0) };
+        R ball_angle = py_mod<R>(angle_degrees<R>(rc, bc, st) + (R)360, (R)360);
+        R ball_dist = m_abs(dist<R>(rc, bc));
+        Seg<R> top = side_of<R>(c, 1), bot = side_of<R>(c, 3);
+        V2<R> mt = { (top.a.x + top.b.x) / (R)2, (top.a.y + top.b.y) / (R)2 }, mb = { (bot.a.x + bot.b.x) / (R)2, (bot.a.y + bot.b.y) / (R)2 };
+        R lf, lb;
+        lidar_serial(q, sp, ridx, mb, mt, lf, lb);
+        o[0] = (O)q.rrot(ridx); o[1] = (O)ball_angle; o[2] = (O)ball_dist; o[3] = (O)lf; o[4] = (O)lb;
+        return 5;
+    }
+    // OBS_V1: SingleBall_6wayLidar (RR_Observers.py:184-285)
+    if (bidx < 0) bidx = 0;
+    Seg<R> fr = side_of<R>(c, 0), bk = side_of<R>(c, 2);
+    V2<R> mf = { (fr.a.x + fr.b.x) / (R)2, (fr.a.y + fr.b.y) / (R)2 }, mbk = { (bk.a.x + bk.b.x) / (R)2, (bk.a.y + bk.b.y) / (R)2 };
+    R lf, lb, lfl, lbr, lfr, lbl;
+    lidar_serial(q, sp, ridx, mbk, mf, lf, lb);
+    lidar_serial(q, sp, ridx, c[BL], c[TR], lfl, lbr);
+    lidar_serial(q, sp, ridx, c[TL], c[BR], lfr, lbl);
+    V2<R> bc = { q.bcx(bidx), q.bcy(bidx) }, good = { sp.W, sp.H }, bad = { (R)0, (R)0 };
+    R ball_angle = angle_degrees<R>(rc, bc, st), ball_dist = dist<R>(rc, bc);
+    R goal_angle = angle_degrees<R>(rc, good, st), bot_angle = q.rrot(ridx), goal_dist;
+    const bool ball_neg = bidx >= C::NBP;
+    if ((team == 1 && !ball_neg) || (team == -1 && ball_neg)) {
+        goal_dist = dist<R>(rc, good);
+    } else {
+        goal_dist = dist<R>(rc, bad);
+        ball_angle = py_mod<R>(ball_angle + (R)180, (R)360);
+        goal_angle = py_mod<R>(goal_angle + (R)180, (R)360);
+        bot_angle = py_mod<R>(bot_angle + (R)180, (R)360);
+    }
+    const R cap = (R)150;
+    o[0] = (O)bot_angle; o[1] = (O)ball_angle; o[2] = (O)py_min<R>(ball_dist, cap); o[3] = (O)goal_angle; o[4] = (O)py_min<R>(goal_dist, cap);
+    o[5] = (O)py_min<R>(lf, cap); o[6] = (O)py_min<R>(lfl, cap); o[7] = (O)py_min<R>(lfr, cap); o[8] = (O)py_min<R>(lb, cap);
+    o[9] = (O)py_min<R>(lbl, cap); o[10] = (O)py_min<R>(lbr, cap);
+    return 11;
+}
+
+} // namespace rr

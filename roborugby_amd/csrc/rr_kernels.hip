@@ -21,6 +21,7 @@
 
 #include "../../include/roborugby_amd.h"
 #include "rr_sim.hpp"
+#include "rr_extras.hpp"
 
 using namespace rr;
 
@@ -208,6 +209,36 @@ __global__ void k_episode_stats(const typename C::Real *recs, const int32_t *ire
     if (cnt) cnt[a] = irec[3 * C::NR + 3];
 }
 
+// ---- other mixins (rr_extras.hpp): thread-per-arena side kernels, straight from the HBM records
+template <class C>
+__global__ void k_extras_begin(const typename C::Real *recs, int n, typename C::Real *xs) {
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    Rec<C> q = { recs + (size_t)a * Arena<C>::P_STRIDE };
+    extras_begin<C>(q, xs + (size_t)a * (3 * C::NR + 1));
+}
+template <class C, typename O>
+__global__ void k_extras_end(SimParams<typename C::Real> sp, const typename C::Real *recs, int n, const typename C::Real *xs,
+                             Program pg, O *reward, O *reward_g, int32_t *status) {
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    const int32_t st = status[a];
+    if (st & (ST_WAS_RESET | ST_STEP_AFTER_DONE)) return; // nothing was stepped: the reward stays 0
+    Rec<C> q = { recs + (size_t)a * Arena<C>::P_STRIDE };
+    extras_end<C, O>(q, sp, xs + (size_t)a * (3 * C::NR + 1), pg, (uint32_t)st >> 16, reward + a, reward_g ? reward_g + a : nullptr,
+                     status + a);
+}
+template <class C, typename O>
+__global__ void k_observe_kind(SimParams<typename C::Real> sp, const typename C::Real *recs, int n, int kind, int team, int ridx,
+                               int bidx, O *obs, int dim) {
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    Rec<C> q = { recs + (size_t)a * Arena<C>::P_STRIDE };
+    O tmp[3 * C::NR + 2 * C::NB > 11 ? 3 * C::NR + 2 * C::NB : 11];
+    const int m = observe_kind<C, O>(q, sp, kind, team, ridx, bidx, tmp);
+    for (int k = 0; k < dim; k++) obs[(size_t)a * dim + k] = k < m ? tmp[k] : (O)NAN;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 // Built configurations: (kind = shape + 2*dtype, entity counts, Real, VW).  The first VW listed for a kind is the
 // default; the environment variable RR_VW selects another built width (kernel tuning / A-B runs).
@@ -226,6 +257,10 @@ struct rr_env {
     size_t rec_bytes, irec_bytes;
     SimParams<double> spd;
     SimParams<float> spf;
+    Program prog;        // reward keepers in execution order
+    bool custom_prog;    // != SimpleDuel3's {Naughty, Chase, PushPos}
+    void *xs;            // on_step_begin snapshot for the side kernels (lazy)
+    int32_t *status_buf; // internal status when the caller passes none but the side kernels need it (lazy)
 };
 
 static thread_local std::string g_err;
@@ -300,6 +335,8 @@ int rr_create(const rr_config *cfg, rr_env **out) {
     e->cfg = *cfg;
     e->kind = shape + 2 * (cfg->dtype == RR_DTYPE_F32 ? 1 : 0);
     e->vw = 0;
+    e->prog.n = 3; e->prog.id[0] = KEEPER_NAUGHTY; e->prog.id[1] = KEEPER_CHASE; e->prog.id[2] = KEEPER_PUSHPOS;
+    e->custom_prog = false; e->xs = nullptr; e->status_buf = nullptr;
     const char *want = getenv("RR_VW");
     const int want_vw = want ? atoi(want) : 0;
 #define X(kind_, a, b, c, d, R_, vw_) \
@@ -344,6 +381,8 @@ int rr_destroy(rr_env *e) {
     (void)hipSetDevice(e->cfg.device);
     (void)hipFree(e->recs);
     (void)hipFree(e->irecs);
+    if (e->xs) (void)hipFree(e->xs);
+    if (e->status_buf) (void)hipFree(e->status_buf);
     delete e;
     return 0;
 }
@@ -372,59 +411,105 @@ static int check_step_args(rr_env *e, const void *act, int32_t na, const void *o
     return 0;
 }
 
-int rr_step(rr_env *e, const int32_t *actions, int32_t na, float *obs, float *reward, uint8_t *done, float *obs_g,
-            float *reward_g, int32_t *status, void *stream) {
-    if (int rc = check_step_args(e, actions, na, obs, reward, done)) return rc;
+// one GameEnv.step for every arena; with a non-default keeper program the side kernels bracket the step kernel
+extern "C++" {
+template <typename O>
+static int step_impl(rr_env *e, const int32_t *actions, const float *thrust, int32_t na, O *obs, O *reward, uint8_t *done,
+                     O *obs_g, O *reward_g, int32_t *status, void *stream) {
     const int n = e->cfg.num_envs;
     DeviceGuard guard(e->cfg.device);
+    hipStream_t s = (hipStream_t)stream;
+    if (e->custom_prog && !status) status = e->status_buf; // the side kernels need the NaughtyBots bits
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
-        hipLaunchKernelGGL((k_step<CC, float>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
-                           (RR *)e->recs, e->irecs, n, actions, (const float *)nullptr, (int)na, obs, reward, done, obs_g,
-                           reward_g, status);
-        return 0;
-    });
-    if (rc) return rc;
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-int rr_step_thrust(rr_env *e, const float *thrust, int32_t nk, float *obs, float *reward, uint8_t *done, float *obs_g,
-                   float *reward_g, int32_t *status, void *stream) {
-    if (int rc = check_step_args(e, thrust, nk, obs, reward, done)) return rc;
-    const int n = e->cfg.num_envs;
-    DeviceGuard guard(e->cfg.device);
-    int rc = dispatch(e, [&](auto c) {
-        using CC = decltype(c); using RR = typename CC::Real;
-        hipLaunchKernelGGL((k_step<CC, float>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
-                           (RR *)e->recs, e->irecs, n, (const int32_t *)nullptr, thrust, (int)nk, obs, reward, done, obs_g,
-                           reward_g, status);
-        return 0;
-    });
-    if (rc) return rc;
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-int rr_step_f64(rr_env *e, const int32_t *actions, int32_t na, double *obs, double *reward, uint8_t *done, double *obs_g,
-                double *reward_g, int32_t *status, void *stream) {
-    if (int rc = check_step_args(e, actions, na, obs, reward, done)) return rc;
-    const int n = e->cfg.num_envs;
-    DeviceGuard guard(e->cfg.device);
-    int rc = dispatch(e, [&](auto c) {
-        using CC = decltype(c); using RR = typename CC::Real;
-        if constexpr (std::is_same<RR, double>::value) {
-            hipLaunchKernelGGL((k_step<CC, double>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
-                               (RR *)e->recs, e->irecs, n, actions, (const float *)nullptr, (int)na, obs, reward, done,
-                               obs_g, reward_g, status);
-            return 0;
+        if constexpr (std::is_same<O, double>::value && !std::is_same<RR, double>::value) {
+            return fail(-1, "fp64 outputs need a handle created with RR_DTYPE_F64");
         } else {
-            return fail(-1, "rr_step_f64: handle was created with RR_DTYPE_F32");
+            if (e->custom_prog)
+                hipLaunchKernelGGL((k_extras_begin<CC>), dim3((n + 127) / 128), dim3(128), 0, s, (const RR *)e->recs, n, (RR *)e->xs);
+            hipLaunchKernelGGL((k_step<CC, O>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (RR *)e->recs, e->irecs, n,
+                               actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status);
+            if (e->custom_prog)
+                hipLaunchKernelGGL((k_extras_end<CC, O>), dim3((n + 127) / 128), dim3(128), 0, s, params_of<RR>(e),
+                                   (const RR *)e->recs, n, (const RR *)e->xs, e->prog, reward, reward_g, status);
+            return 0;
         }
     });
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
+}
+} // extern "C++"
+
+int rr_step(rr_env *e, const int32_t *actions, int32_t na, float *obs, float *reward, uint8_t *done, float *obs_g,
+            float *reward_g, int32_t *status, void *stream) {
+    if (int rc = check_step_args(e, actions, na, obs, reward, done)) return rc;
+    return step_impl<float>(e, actions, nullptr, na, obs, reward, done, obs_g, reward_g, status, stream);
+}
+int rr_step_thrust(rr_env *e, const float *thrust, int32_t nk, float *obs, float *reward, uint8_t *done, float *obs_g,
+                   float *reward_g, int32_t *status, void *stream) {
+    if (int rc = check_step_args(e, thrust, nk, obs, reward, done)) return rc;
+    return step_impl<float>(e, nullptr, thrust, nk, obs, reward, done, obs_g, reward_g, status, stream);
+}
+int rr_step_f64(rr_env *e, const int32_t *actions, int32_t na, double *obs, double *reward, uint8_t *done, double *obs_g,
+                double *reward_g, int32_t *status, void *stream) {
+    if (int rc = check_step_args(e, actions, na, obs, reward, done)) return rc;
+    return step_impl<double>(e, actions, nullptr, na, obs, reward, done, obs_g, reward_g, status, stream);
+}
+
+int rr_set_reward_program(rr_env *e, const int32_t *ids, int32_t n) {
+    if (!e || (!ids && n > 0)) return fail(-1, "rr_set_reward_program: null argument");
+    if (n < 0 || n > 8) return fail(-1, "rr_set_reward_program: at most 8 keepers");
+    for (int i = 0; i < n; i++)
+        if (ids[i] < KEEPER_NAUGHTY || ids[i] > KEEPER_PUSHNEG) return fail(-1, "rr_set_reward_program: unknown keeper id");
+    DeviceGuard guard(e->cfg.device);
+    e->prog.n = n;
+    for (int i = 0; i < n; i++) e->prog.id[i] = ids[i];
+    e->custom_prog = !(n == 3 && ids[0] == KEEPER_NAUGHTY && ids[1] == KEEPER_CHASE && ids[2] == KEEPER_PUSHPOS);
+    if (e->custom_prog && !e->xs) { // allocated here, never inside rr_step (keeps the step launch-only)
+        const size_t rsz = e->cfg.dtype == RR_DTYPE_F32 ? 4 : 8;
+        const size_t nr = (size_t)(e->cfg.nr_happy + e->cfg.nr_grumpy);
+        HIP_TRY(hipMalloc(&e->xs, rsz * (3 * nr + 1) * (size_t)e->cfg.num_envs));
+        HIP_TRY(hipMalloc((void **)&e->status_buf, sizeof(int32_t) * (size_t)e->cfg.num_envs));
+    }
+    return 0;
+}
+
+extern "C++" {
+template <typename O>
+static int observe_kind_impl(rr_env *e, int32_t kind, int32_t team, int32_t ridx, int32_t bidx, O *obs, int32_t out_dim, void *stream) {
+    if (!e || !obs) return fail(-1, "rr_observe_kind: null argument");
+    const int nr = e->cfg.nr_happy + e->cfg.nr_grumpy, nb = e->cfg.nb_pos + e->cfg.nb_neg;
+    if ((team != 1 && team != -1) || ridx >= nr || bidx >= nb) return fail(-1, "rr_observe_kind: bad team/robot/ball index");
+    const int want = kind == OBS_V2 || kind == OBS_V1 ? 11 : kind == OBS_BASIC ? 5 : kind == OBS_ALLCOORDS ? 3 * nr + 2 * nb : -1;
+    if (want < 0) return fail(-1, "rr_observe_kind: unknown observer kind");
+    if (out_dim != want) return fail(-1, "rr_observe_kind: out_dim does not match the observer's size");
+    const int n = e->cfg.num_envs;
+    DeviceGuard guard(e->cfg.device);
+    int rc = dispatch(e, [&](auto c) {
+        using CC = decltype(c); using RR = typename CC::Real;
+        if constexpr (std::is_same<O, double>::value && !std::is_same<RR, double>::value) {
+            return fail(-1, "fp64 outputs need a handle created with RR_DTYPE_F64");
+        } else {
+            if (kind == OBS_V2)
+                hipLaunchKernelGGL((k_observe<CC, O>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
+                                   (const RR *)e->recs, (const int32_t *)e->irecs, n, (int)team, (int)ridx, (int)bidx, obs);
+            else
+                hipLaunchKernelGGL((k_observe_kind<CC, O>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, params_of<RR>(e),
+                                   (const RR *)e->recs, n, (int)kind, (int)team, (int)ridx, (int)bidx, obs, (int)out_dim);
+            return 0;
+        }
+    });
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+} // extern "C++"
+int rr_observe_kind(rr_env *e, int32_t kind, int32_t team, int32_t ridx, int32_t bidx, float *obs, int32_t out_dim, void *stream) {
+    return observe_kind_impl<float>(e, kind, team, ridx, bidx, obs, out_dim, stream);
+}
+int rr_observe_kind_f64(rr_env *e, int32_t kind, int32_t team, int32_t ridx, int32_t bidx, double *obs, int32_t out_dim, void *stream) {
+    return observe_kind_impl<double>(e, kind, team, ridx, bidx, obs, out_dim, stream);
 }
 
 static int check_obs_args(rr_env *e, const void *obs, int32_t team, int32_t ridx, int32_t bidx) {

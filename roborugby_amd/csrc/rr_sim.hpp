@@ -1485,7 +1485,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     if (RR_IS_LANE0) {
         *o.reward = (O)rew_h; *o.done = done ? 1 : 0;
         if (o.reward_g) *o.reward_g = (O)rew_g;
-        if (o.status) *o.status = st;
+        if (o.status) *o.status = st | (int)(naughty << 16); // bits 16..: robots NaughtyBots flagged this step
         // episode bookkeeping for logging (the caller sums `score` the same way, Training_DQN_pytorch.py:345-346)
         A.p.acc[0] += rew_h; A.p.acc[1] += rew_g; A.i.ep_len += 1;
         if (done) { A.p.acc[2] = A.p.acc[0]; A.p.acc[3] = A.p.acc[1]; A.i.last_len = A.i.ep_len; A.i.ep_count += 1; }

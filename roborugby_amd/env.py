@@ -29,6 +29,26 @@ STATUS_BITS = {
     128: "action outside Direction 0..7",                 # KeyError at RR_EnvBase.py:606
 }
 STATUS_WARN, STATUS_RESET_GAVE_UP, STATUS_WAS_RESET = 256, 512, 1024
+STATUS_FLAG_MASK, STATUS_NAUGHTY_SHIFT = 0xFFFF, 16  # info.status: flags in bits 0-15, NaughtyBots' robots in bits 16+
+
+# reward mixins of RR_ScoreKeepers.py (ids of the C-ABI's keeper program) and observer mixins of RR_Observers.py
+KEEPERS = {"NaughtyBots": 1, "ChasePosBall": 2, "PushPosBallsToGoal": 3, "DontDriveInGoals": 4, "KeepMovingGuys": 5,
+           "BaseDestruction": 6, "PushNegBallsFromGoal": 7}
+OBSERVERS = {"SingleBall_6wayLidar_v2": 0, "SingleBall_6wayLidar": 1, "PosBall_BasicLidar": 2, "AllCoords": 3}
+SIMPLE_DUEL3_REWARDS = ("PushPosBallsToGoal", "ChasePosBall", "NaughtyBots")  # RR_Environments.py:27-32
+
+
+def keeper_exec_order(mro_names):
+    """on_step_end execution order of a keeper stack given in class (MRO) order: every keeper calls super() first --
+    so the LAST one listed runs first -- except NaughtyBots, whose on_step_end never calls super()
+    (RR_ScoreKeepers.py:130-135): keepers listed after it do not run at all."""
+    names = list(mro_names)
+    for n in names:
+        if n not in KEEPERS:
+            raise KeyError(f"unknown score keeper {n!r}; available: {sorted(KEEPERS)}")
+    if "NaughtyBots" in names:
+        names = names[:names.index("NaughtyBots") + 1]
+    return [KEEPERS[n] for n in reversed(names)]
 
 
 class Direction:  # GameEnv_Simple.Direction (RR_EnvBase.py:583-591)
@@ -53,7 +73,8 @@ class BatchedRoboRugbyEnv:
     """N lockstep arenas of SimpleDuel3 on one MI355X.
 
     reset() -> obs float32[N,11];  step(actions) -> (obs float32[N,11], reward float32[N], done bool[N], info)
-    with info.adblGrumpyState float32[N,11] | None, info.dblGrumpyScore float32[N], info.status int32[N].
+    with info.adblGrumpyState float32[N,11] | None, info.dblGrumpyScore float32[N], info.status int32[N] (fault / reset flags
+    in bits 0-15, the robots NaughtyBots flagged this step in bits 16+).
 
     time_limit=True reports done when step_count == max_episode_steps like gym's TimeLimit wrapper does for the
     DQN script; False is the raw env rule (step_count > T, RR_EnvBase.py:555-559).  With auto_reset=True a step
@@ -66,7 +87,8 @@ class BatchedRoboRugbyEnv:
     reward_range = (-float("inf"), float("inf"))
 
     def __init__(self, num_envs, preset="T", device=None, seed=0, time_limit=True, auto_reset=True, dtype="f64",
-                 arena_offset=0, env_id="RoboRugbySimpleDuel-v3", reset_on_fault=None, action_mode="discrete"):
+                 arena_offset=0, env_id="RoboRugbySimpleDuel-v3", reset_on_fault=None, action_mode="discrete",
+                 rewards=SIMPLE_DUEL3_REWARDS, observer="SingleBall_6wayLidar_v2"):
         self.preset = PRESETS[preset] if isinstance(preset, str) else preset
         assert isinstance(self.preset, Preset)
         if not torch.cuda.is_available():
@@ -93,8 +115,19 @@ class BatchedRoboRugbyEnv:
         h = C.c_void_p()
         _lib.check(self._lib.rr_create(C.byref(cfg), C.byref(h)), "rr_create")
         self._h = h
+        # other mixin stacks of the reference: `rewards` in class order like the reference's env classes
+        # (RR_Environments.py), `observer` one of OBSERVERS.  SimpleDuel3's own stack is the default and stays fused in
+        # the step kernel; anything else runs in light side kernels around it.
+        if observer not in OBSERVERS:
+            raise KeyError(f"unknown observer {observer!r}; available: {sorted(OBSERVERS)}")
+        self.observer, self.obs_kind = observer, OBSERVERS[observer]
+        self.obs_dim = {0: 11, 1: 11, 2: 5, 3: 3 * p.nr + 2 * p.nb}[self.obs_kind]
+        self.rewards = tuple(rewards)
+        prog = np.asarray(keeper_exec_order(self.rewards), np.int32)
+        _lib.check(self._lib.rr_set_reward_program(self._h, prog.ctypes.data_as(C.c_void_p), len(prog)),
+                   "rr_set_reward_program")
         m = max(p.arena_w, p.arena_h, 360)  # RR_Observers.py:30-37
-        self.observation_space = Box(-m, m, (11,), np.float32)
+        self.observation_space = Box(-m, m, (self.obs_dim,), np.float32)
         # GameEnv_Simple: Discrete(8) (RR_EnvBase.py:610); bare GameEnv: Box(-1, 1, (2*happy robots,)) (RR_EnvBase.py:118-123),
         # the surface Training_SAC_pytorch.py:270,423 reads (`action_space.high`, `.shape[0]`)
         if action_mode not in ("discrete", "thrust"):
@@ -126,7 +159,7 @@ class BatchedRoboRugbyEnv:
             # rows that are not reset keep their current observation
             _lib.check(self._lib.rr_observe(self._h, 1, -1, -1, _ptr(obs), self._stream()), "rr_observe")
         _lib.check(self._lib.rr_reset(self._h, _ptr(mask), _ptr(obs), None, self._stream()), "rr_reset")
-        return obs
+        return obs if self.obs_kind == 0 else self.get_game_state(1)
 
     def step(self, actions, out=None):
         """GameEnv_Simple.step for every arena.  actions: int tensor [N] or [N,NA] (NA <= robots; action i drives
@@ -153,6 +186,8 @@ class BatchedRoboRugbyEnv:
             obs, rew, done, obs_g, rew_g, status = out
         _lib.check(self._lib.rr_step(self._h, _ptr(a), a.shape[1], _ptr(obs), _ptr(rew), _ptr(done), _ptr(obs_g),
                                      _ptr(rew_g), _ptr(status), self._stream()), "rr_step")
+        if self.obs_kind != 0:
+            obs, obs_g = self.get_game_state(1), (self.get_game_state(-1) if self.has_grumpy else None)
         return obs, rew, done.view(torch.bool), DebugInfo(obs_g, rew_g, status)
 
     def step_thrust(self, thrust):
@@ -167,6 +202,8 @@ class BatchedRoboRugbyEnv:
         rew_g, status = self._new((N,), torch.float32), self._new((N,), torch.int32)
         _lib.check(self._lib.rr_step_thrust(self._h, _ptr(t), t.shape[1] // 2, _ptr(obs), _ptr(rew), _ptr(done),
                                             _ptr(obs_g), _ptr(rew_g), _ptr(status), self._stream()), "rr_step_thrust")
+        if self.obs_kind != 0:
+            obs, obs_g = self.get_game_state(1), (self.get_game_state(-1) if self.has_grumpy else None)
         return obs, rew, done.view(torch.bool), DebugInfo(obs_g, rew_g, status)
 
     def step_f64(self, actions):
@@ -182,14 +219,17 @@ class BatchedRoboRugbyEnv:
                                          _ptr(rew_g), _ptr(status), self._stream()), "rr_step_f64")
         return obs, rew, done.view(torch.bool), DebugInfo(obs_g, rew_g, status)
 
-    def get_game_state(self, int_team=None, robot_idx=-1, ball_idx=-1, f64=False):
-        """SingleBall_6wayLidar_v2.get_game_state (RR_Observers.py:301-406); None when the team has no robot."""
+    def get_game_state(self, int_team=None, robot_idx=-1, ball_idx=-1, f64=False, observer=None):
+        """get_game_state of the configured (or named) observer mixin (RR_Observers.py); None when the reference
+        returns None (the team has no robot)."""
         team = 1 if int_team is None else int(int_team)
-        if robot_idx < 0 and ((team == 1 and self.preset.nr_happy == 0) or (team == -1 and self.preset.nr_grumpy == 0)):
+        kind = self.obs_kind if observer is None else OBSERVERS[observer]
+        if kind != 3 and robot_idx < 0 and ((team == 1 and self.preset.nr_happy == 0) or (team == -1 and self.preset.nr_grumpy == 0)):
             return None
-        obs = self._new((self.num_envs, 11), torch.float64 if f64 else torch.float32)
-        fn = self._lib.rr_observe_f64 if f64 else self._lib.rr_observe
-        _lib.check(fn(self._h, team, int(robot_idx), int(ball_idx), _ptr(obs), self._stream()), "rr_observe")
+        dim = {0: 11, 1: 11, 2: 5, 3: 3 * self.preset.nr + 2 * self.preset.nb}[kind]
+        obs = self._new((self.num_envs, dim), torch.float64 if f64 else torch.float32)
+        fn = self._lib.rr_observe_kind_f64 if f64 else self._lib.rr_observe_kind
+        _lib.check(fn(self._h, kind, team, int(robot_idx), int(ball_idx), _ptr(obs), dim, self._stream()), "rr_observe_kind")
         return obs
 
     def render(self, mode="human", arena=0):
@@ -303,7 +343,7 @@ class RoboRugbyEnv:
             if len(arr) > self.preset.nr:
                 raise Exception(f"{len(arr)} commands but only {self.preset.nr} robots.")
             obs, rew, done, info = self._b.step(torch.as_tensor(arr.astype(np.int64)).view(1, -1))
-        st = int(info.status[0])
+        st = int(info.status[0]) & STATUS_FLAG_MASK
         for bit, msg in STATUS_BITS.items():
             if st & bit:
                 raise ZeroDivisionError(msg) if bit == 32 else Exception(msg)

@@ -7,6 +7,7 @@ static int g_dbg_trace = 0;
 #define RR_NUM_SUBSTEPS g_dbg_substeps
 #define RR_EMU_TRACE g_dbg_trace
 #include "../../roborugby_amd/csrc/rr_sim.hpp"
+#include "../../roborugby_amd/csrc/rr_extras.hpp"
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -16,6 +17,8 @@ using namespace rr;
 template <class C> struct Emu {
     Arena<C> A;
     SimParams<typename C::Real> sp;
+    Program prog;     // reward keepers in execution order (default = SimpleDuel3)
+    bool custom_prog;
 };
 
 template <typename R> static void fill_params(SimParams<R> &sp, double W, double H, int game_len, int game_mode,
@@ -103,6 +106,7 @@ Handle *emu_create(int preset, int f32, double W, double H, int game_len, int ga
     default: h->p = calloc(1, sizeof(Emu<CG64n>)); break;
     }
     DISPATCH(h, fill_params(e->sp, W, H, game_len, game_mode, time_limit, auto_reset, seed); (void)sizeof(CC);
+             e->prog.n = 3; e->prog.id[0] = 1; e->prog.id[1] = 2; e->prog.id[2] = 3; e->custom_prog = false;
              for (int r = 0; r < CC::NR; r++) robot_set_clean_lane(e->A, e->sp, r, (typename CC::Real)0, (typename CC::Real)0,
                                                                    r < CC::NRH ? (typename CC::Real)90 : (typename CC::Real)-90);
              for (int b = 0; b < CC::NB; b++) ball_set_clean_lane(e->A, b, (typename CC::Real)0, (typename CC::Real)0,
@@ -124,19 +128,44 @@ void emu_set_poses(Handle *h, const double *rxyr, const double *bxyv) {
                                                                   (typename CC::Real)bxyv[4 * b + 2], (typename CC::Real)bxyv[4 * b + 3]);
              e->A.i.step = 0; derive(e->A, e->sp));
 }
+// same bracketing as rr_step: snapshot -> step kernel phases -> keeper program (only for a non-default program)
+extern "C++" {
+template <class CC> static int emu_step_t(Emu<CC> *e, const int32_t *actions, const float *thrust, int na, double *obs,
+                                          double *obs_g, double *reward, double *reward_g, uint8_t *done) {
+    using RR = typename CC::Real;
+    int32_t status = 0;
+    RR xs[3 * CC::NR + 1];
+    Rec<CC> q = { reinterpret_cast<const RR *>(&e->A.p) };
+    if (e->custom_prog) extras_begin<CC>(q, xs);
+    StepOut<double> o = { obs, obs_g, reward, reward_g, done, &status };
+    step_arena<CC, double>(e->A, e->sp, 0, actions, thrust, na, o);
+    if (e->custom_prog && !(status & (ST_WAS_RESET | ST_STEP_AFTER_DONE)))
+        extras_end<CC, double>(q, e->sp, xs, e->prog, (uint32_t)status >> 16, reward, reward_g, &status);
+    return status;
+}
+} // extern "C++"
 int emu_step(Handle *h, const int32_t *actions, int na, double *obs, double *obs_g, double *reward, double *reward_g,
              uint8_t *done) {
     int32_t status = 0;
-    StepOut<double> o = { obs, obs_g, reward, reward_g, done, &status };
-    DISPATCH(h, step_arena<CC, double>(e->A, e->sp, 0, actions, nullptr, na, o));
+    DISPATCH(h, status = emu_step_t<CC>(e, actions, nullptr, na, obs, obs_g, reward, reward_g, done));
     return status;
 }
 int emu_step_thrust(Handle *h, const float *thrust, int nk, double *obs, double *obs_g, double *reward, double *reward_g,
                     uint8_t *done) {
     int32_t status = 0;
-    StepOut<double> o = { obs, obs_g, reward, reward_g, done, &status };
-    DISPATCH(h, step_arena<CC, double>(e->A, e->sp, 0, nullptr, thrust, nk, o));
+    DISPATCH(h, status = emu_step_t<CC>(e, nullptr, thrust, nk, obs, obs_g, reward, reward_g, done));
     return status;
+}
+void emu_set_program(Handle *h, const int32_t *ids, int n) {
+    DISPATCH(h, e->prog.n = n; for (int i = 0; i < n; i++) e->prog.id[i] = ids[i];
+             e->custom_prog = !(n == 3 && ids[0] == 1 && ids[1] == 2 && ids[2] == 3));
+}
+int emu_observe_kind(Handle *h, int kind, int team, int ridx, int bidx, double *out) {
+    int m = 0;
+    DISPATCH(h, if (kind == 0) { int st = 0; m = observe<CC, double>(e->A, e->sp, team, ridx, bidx, out, st) ? 11 : 0; }
+                else { Rec<CC> q = { reinterpret_cast<const typename CC::Real *>(&e->A.p) };
+                       m = observe_kind<CC, double>(q, e->sp, kind, team, ridx, bidx, out); });
+    return m;
 }
 int emu_observe(Handle *h, int team, int ridx, int bidx, double *obs) {
     int st = 0, ok = 0;

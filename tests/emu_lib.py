@@ -39,6 +39,8 @@ def lib():
         L.emu_step_thrust.argtypes = [C.c_void_p, fp, C.c_int, dp, dp, dp, dp, u8p]
         L.emu_observe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, dp]
         L.emu_reset.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        L.emu_set_program.argtypes = [C.c_void_p, ip, C.c_int]
+        L.emu_observe_kind.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp]
         _lib = L
     return _lib
 
@@ -91,7 +93,18 @@ class EmuEnv:
         done = np.zeros(1, np.uint8)
         st = lib().emu_step(self.h, _ip(a), len(a), _dp(obs), _dp(obs_g), _dp(rew), _dp(rew_g),
                             done.ctypes.data_as(C.POINTER(C.c_uint8)))
-        return dict(obs=obs, obs_g=obs_g, reward=float(rew[0]), reward_g=float(rew_g[0]), done=bool(done[0]), status=int(st))
+        # status word: flags in bits 0-15, NaughtyBots' robot set in bits 16+
+        return dict(obs=obs, obs_g=obs_g, reward=float(rew[0]), reward_g=float(rew_g[0]), done=bool(done[0]),
+                    status=int(st) & 0xFFFF, naughty=(int(st) >> 16) & 0xFF)
+
+    def set_program(self, ids):
+        a = np.ascontiguousarray(ids, np.int32)
+        lib().emu_set_program(self.h, _ip(a), len(a))
+
+    def observe_kind(self, kind, team=1, robot=-1, ball=-1):
+        o = np.zeros(64)
+        n = lib().emu_observe_kind(self.h, kind, team, robot, ball, _dp(o))
+        return o[:n].copy() if n > 0 else None
 
     def step_thrust(self, thrust):
         t = np.ascontiguousarray(np.asarray(thrust, np.float32).reshape(-1))
@@ -99,7 +112,8 @@ class EmuEnv:
         done = np.zeros(1, np.uint8)
         st = lib().emu_step_thrust(self.h, t.ctypes.data_as(C.POINTER(C.c_float)), len(t) // 2, _dp(obs), _dp(obs_g),
                                    _dp(rew), _dp(rew_g), done.ctypes.data_as(C.POINTER(C.c_uint8)))
-        return dict(obs=obs, obs_g=obs_g, reward=float(rew[0]), reward_g=float(rew_g[0]), done=bool(done[0]), status=int(st))
+        return dict(obs=obs, obs_g=obs_g, reward=float(rew[0]), reward_g=float(rew_g[0]), done=bool(done[0]),
+                    status=int(st) & 0xFFFF, naughty=(int(st) >> 16) & 0xFF)
 
     def observe(self, team=1, robot=-1, ball=-1):
         o = np.zeros(11)

@@ -42,6 +42,8 @@ def lib():
         L.rro_set_clean_state.argtypes = [C.c_void_p, dp, dp, C.c_int32]
         L.rro_observe.argtypes = [C.c_void_p, C.c_int, dp]
         L.rro_observe_for.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, dp]
+        L.rro_observe_kind.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+        L.rro_set_program.argtypes = [C.c_void_p, ip, C.c_int]
         L.rro_step.argtypes = [C.c_void_p, ip, C.c_int, dp, dp, dp, dp, u8p, ip]
         L.rro_step_thrust.argtypes = [C.c_void_p, dp, C.c_int, dp, dp, dp, dp, u8p, ip]
         L.rro_reset.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
@@ -113,6 +115,18 @@ class OracleEnv:
         o = np.zeros(11)
         ok = lib().rro_observe_for(self.h, team, robot, ball, _dp(o))
         return o if ok else None
+
+    def set_program(self, ids):
+        """Reward keepers in on_step_end execution order (1 Naughty, 2 Chase, 3 PushPos, 4 DontDrive, 5 KeepMoving,
+        6 BaseDestruction, 7 PushNeg); default = SimpleDuel3's (1, 2, 3)."""
+        a = np.ascontiguousarray(ids, np.int32)
+        lib().rro_set_program(self.h, _ip(a), len(a))
+
+    def observe_kind(self, kind, team=1, robot=-1, ball=-1):
+        """kind 0 = SingleBall_6wayLidar_v2, 1 = SingleBall_6wayLidar, 2 = PosBall_BasicLidar, 3 = AllCoords."""
+        o = np.zeros(64)
+        n = lib().rro_observe_kind(self.h, kind, team, robot, ball, _dp(o))
+        return o[:n].copy() if n > 0 else None
 
     def step(self, actions):
         a = np.ascontiguousarray(np.asarray(actions).reshape(-1), np.int32)

@@ -78,7 +78,7 @@ def test_gpu_kernel_vs_oracle_on_adversarial_states(preset, n):
     ok = faults = knife = 0
     for a in range(0, n, 5):
         res, ost = adv.oracle_step(preset, robots[a], balls[a], actions[a])
-        g_res = dict(status=int(status[a]), obs=o[a], reward=float(r[a]), done=bool(d[a]))
+        g_res = dict(status=int(status[a]) & 0xFFFF, obs=o[a], reward=float(r[a]), done=bool(d[a]))
         g_st = {k: st[k][a] for k in ("robots", "robots_i", "balls")}
         v = _compare(preset, res, ost, g_res, g_st, (preset, a), (robots[a], balls[a], actions[a]))
         ok += v == "ok"

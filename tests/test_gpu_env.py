@@ -209,7 +209,7 @@ def test_f32_mode_runs_and_tracks_f64():
     o32, r32, _, _ = e32.step(a)
     err = (o64 - o32).abs().max(dim=1).values
     assert float(err.median()) < 1e-2 and float((err > 1.0).float().mean()) < 0.03
-    with pytest.raises(Exception, match="RR_DTYPE_F32"):
+    with pytest.raises(Exception, match="RR_DTYPE_F64"):
         e32.step_f64(a)
 
 

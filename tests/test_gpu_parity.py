@@ -30,7 +30,7 @@ def _flatten_golden(t):
     s = np.array([i[1] for i in idx])
     pre = {k: t["state_" + k][ep, s] for k in ("robots", "robots_i", "balls", "step")}
     post = {k: t["state_" + k][ep, s + 1] for k in ("robots", "robots_i", "balls", "step")}
-    out = {k: t[k][ep, s] for k in ("actions", "obs", "obs_g", "reward", "reward_g", "done")}
+    out = {k: t[k][ep, s] for k in ("actions", "obs", "obs_g", "reward", "reward_g", "done", "naughty")}
     return pre, post, out
 
 
@@ -70,7 +70,9 @@ def test_step_matches_reference_golden_f64(golden_dir, preset):
         assert np.array_equal(d.astype(np.uint8), out["done"][sel])
         if og is not None:
             do = max(do, np.abs(og - out["obs_g"][sel]).max())
-        assert (status & ~256).max() == 0
+        assert (status & 0xFFFF & ~256).max() == 0
+        if "naughty" in out:  # the robots NaughtyBots flagged travel in status bits 16+: exact
+            assert np.array_equal((status >> 16) & 0xFF, out["naughty"][sel])
         worst = max(worst, dr, db, do, drw)
         assert dr < TOL64 and db < TOL64 and do < TOL64 and drw < 1e-7, (preset, k, dr, db, do, drw)
     print(f"[{preset}] {n} golden steps replayed on GPU, worst abs diff {worst:.3e}")
