@@ -59,9 +59,16 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise ImportError(
-            f"{LIB_PATH} is missing: build the gfx950 library first (python -m roborugby_amd.build). "
-            "roborugby_amd has no CPU fallback.")
+        # not a fallback: the only thing ever loaded is the HIP library, built here if the in-tree .so is absent
+        try:
+            if "RR_LIB_PATH" in os.environ:
+                raise RuntimeError("RR_LIB_PATH points to a missing file")
+            from .build import build_hip_library
+            build_hip_library(verbose=True)
+        except Exception as exc:
+            raise ImportError(
+                f"{LIB_PATH} is missing and could not be built ({exc}): run `python -m roborugby_amd.build`. "
+                "roborugby_amd has no CPU fallback.") from exc
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

@@ -290,6 +290,11 @@ class BatchedRoboRugbyEnv:
         _lib.check(self._lib.rr_set_poses(self._h, _ptr(r), _ptr(b), self._stream()), "rr_set_poses")
         torch.cuda.current_stream(self.device).synchronize()
 
+    def goal_scores(self):
+        """Goal.get_score() of (happy, grumpy) goal (RR_Goal.py:87-88): identically 0 on the live path -- the reference
+        never feeds its goal bookkeeping, so `done` is purely the step counter."""
+        return torch.zeros((self.num_envs, 2), dtype=torch.int32, device=self.device)
+
     def episode_stats(self):
         """(last finished episode return happy, grumpy, its length, number of finished episodes) per arena."""
         N = self.num_envs
