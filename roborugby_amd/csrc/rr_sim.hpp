@@ -1044,39 +1044,36 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     uint32_t bots_moved = (1u << C::NR) - 1, balls_moved = (1u << C::NB) - 1;
     RR_TRACE("E substep\n");
     RR_T0();
+    // phase 1: frame hooks, robot moves AND the exact broad phase.  The broad phase runs in the same phase as the moves:
+    // it may see a robot centre from before or after this sub-step's move, so its bounds carry the largest centre
+    // displacement a move can cause (1 px drive / 0.17 px pivot / <= 1.5 px wall clamp: 3 px per robot is generous).
+    uint64_t m_rr = 0, m_br = 0;
     RR_FOR_LANES(l) {
+        bool c_rr = false, c_br = false;
         if (l < C::NR) {
             if (prev_moved & (1u << l)) { A.p.px[l] = A.ax[l]; A.p.py[l] = A.ay[l]; A.p.prot[l] = A.arot[l]; }
             // on_frame_begin (RR_Robot.py:119-120): the ring entry written this frame
-            A.ax[l] = A.p.rcx[l]; A.ay[l] = A.p.rcy[l]; A.arot[l] = A.p.rrot[l];
+            const R ox = A.p.rcx[l], oy = A.p.rcy[l];
+            A.ax[l] = ox; A.ay[l] = oy; A.arot[l] = A.p.rrot[l];
+            for (int j = 0; j < C::NR; j++) { // robot-robot: needs centres within 2 x 22.36 (+ 2 x 3 px of motion)
+                R dx = A.p.rcx[j] - ox, dy = A.p.rcy[j] - oy;
+                c_rr = c_rr | ((j > l) & (dx * dx + dy * dy <= (R)(51.5 * 51.5)));
+            }
             robot_move_lane(A, sp, l); // _move_bots
         }
         if (l < C::NB) { // on_frame_begin (RR_Ball.py:63-68)
             A.bmass[l] = 1; A.bfx[l] = (R)0; A.bfy[l] = (R)0;
             A.pfx[l] = ball_copy_c<R>(A.p.bcx[l]); A.pfy[l] = ball_copy_c<R>(A.p.bcy[l]);
-        }
-    }
-    RR_SYNC();
-    RR_STAMP(1);
-    // fused exact broad phase: robot lanes against the later robots, ball lanes against every robot
-    uint64_t m_rr = 0, m_br = 0;
-    RR_FOR_LANES(l) {
-        bool c_rr = false, c_br = false;
-        if (l < C::NR) {
-            for (int j = 0; j < C::NR; j++) {
-                R dx = A.p.rcx[j] - A.p.rcx[l], dy = A.p.rcy[j] - A.p.rcy[l];
-                c_rr = c_rr | ((j > l) & (dx * dx + dy * dy <= cull_rr2<R>()));
-            }
-        }
-        if (l < C::NB) {
-            for (int r = 0; r < C::NR; r++) {
+            for (int r = 0; r < C::NR; r++) { // ball-robot: 22.36 + 9.9 (+ 3 px of robot motion)
                 R dx = A.p.bcx[l] - A.p.rcx[r], dy = A.p.bcy[l] - A.p.rcy[r];
-                c_br = c_br | (dx * dx + dy * dy <= cull_br2<R>());
+                c_br = c_br | (dx * dx + dy * dy <= (R)(36.0 * 36.0));
             }
         }
         RR_VOTE(m_rr, l, c_rr);
         RR_VOTE(m_br, l, c_br);
     }
+    RR_SYNC();
+    RR_STAMP(1);
     if (m_rr) {
         resolve_bot_collisions(A, sp, bots_moved, naughty, st);
         m_br = 1; // an undone robot changes the ball-robot picture: let the full detection decide
@@ -1093,29 +1090,32 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
         }
     }
     RR_STAMP(3);
-    RR_FOR_LANES(l) { // _roll_balls
-        if (l < C::NB) ball_move_lane(A, l);
-    }
-    RR_SYNC();
-    RR_STAMP(4);
-    // fused first pass of _resolve_ball_collisions: anything possibly touching?  (ball-ball within the sqrt test's
-    // reach, ball-robot within the broad-phase bound, the exact int-rect wall test)
+    // phase 2: _roll_balls AND the fused first pass of _resolve_ball_collisions: anything possibly touching?  Ball-ball
+    // runs in the same phase as the roll, so the other ball may be seen before or after its own roll: the bound adds
+    // the most it can still travel (|v| + |force| per axis, +1 % and the 0.005 dead band for a velocity read after its
+    // damping).  Ball-robot uses the settled robot centres; the wall test is the exact int-rect test.
     uint64_t m_any = 0;
     RR_FOR_LANES(l) {
         bool c = false;
         if (l < C::NB) {
+            ball_move_lane(A, l);
+            const R mx = A.p.bcx[l], my = A.p.bcy[l];
             for (int j = 0; j < C::NB; j++) {
-                R dx = A.p.bcx[j] - A.p.bcx[l], dy = A.p.bcy[j] - A.p.bcy[l];
-                c = c | ((j > l) & (dx * dx + dy * dy <= (R)197));
+                R dx = A.p.bcx[j] - mx, dy = A.p.bcy[j] - my;
+                R tr = (m_abs(A.p.bvx[j]) + m_abs(A.bfx[j]) + m_abs(A.p.bvy[j]) + m_abs(A.bfy[j])) * (R)1.01 + (R)0.02;
+                R reach = (R)14.04 + tr;
+                c = c | ((j != l) & (dx * dx + dy * dy <= reach * reach));
             }
             for (int r = 0; r < C::NR; r++) {
-                R dx = A.p.bcx[l] - A.p.rcx[r], dy = A.p.bcy[l] - A.p.rcy[r];
+                R dx = mx - A.p.rcx[r], dy = my - A.p.rcy[r];
                 c = c | (dx * dx + dy * dy <= cull_br2<R>());
             }
             c = c | ball_collided_wall(A, sp, l);
         }
         RR_VOTE(m_any, l, c);
     }
+    RR_SYNC();
+    RR_STAMP(4);
     if (m_any) { // the reference's loop, from its first pass (nothing has changed since the broad phase above)
         bool rr_ok_ = resolve_ball_collisions(A, sp, bots_moved, st);
         RR_STAMP(5);
