@@ -659,10 +659,12 @@ template <class C>
 RR_HD void robot_prev_frame(const Arena<C> &A, const SimParams<typename C::Real> &sp, int r, uint32_t bots_moved,
                             typename C::Real &x, typename C::Real &y, typename C::Real *rel) {
     using R = typename C::Real;
+    // rectPrior = rectDbl.copy(): centre c' = 10 + (cx - 10); then `rectPrior.center = (x, y)` moves it by (x - c')
+    const R ccx = (R)10 + (A.p.rcx[r] - (R)10), ccy = (R)20 + (A.p.rcy[r] - (R)20);
     R rot;
-    if (bots_moved & (1u << r)) { x = A.ax[r]; y = A.ay[r]; rot = A.arot[r]; }
-    else if (!is_nan(A.p.px[r])) { x = A.p.px[r]; y = A.p.py[r]; rot = A.p.prot[r]; }
-    else { x = A.p.rcx[r]; y = A.p.rcy[r]; rot = A.p.rrot[r]; }
+    if (bots_moved & (1u << r)) { x = ccx + (A.ax[r] - ccx); y = ccy + (A.ay[r] - ccy); rot = A.arot[r]; }
+    else if (!is_nan(A.p.px[r])) { x = ccx + (A.p.px[r] - ccx); y = ccy + (A.p.py[r] - ccy); rot = A.p.prot[r]; }
+    else { x = ccx; y = ccy; rot = A.p.rrot[r]; }
     corners_for<R>(py_mod<R>(rot + (R)720, (R)360), (R)10, (R)20, sp.rob_cdist, rel);
 }
 template <class C> RR_HD void force_diameters(const Arena<C> &A, int r, V2<typename C::Real> bc, Seg<typename C::Real> dia[2]) {
@@ -1417,7 +1419,8 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     RR_SYNC();
     RR_FOR_LANES(l) {
         if (l < C::NR) {
-            A.psx[l] = A.p.rcx[l]; A.psy[l] = A.p.rcy[l];
+            // rectDblPriorStep = rectDbl.copy(): a fresh 20x40 rect centred at (10,20) moved by the centre setters (MyUtils.py:150-154)
+            A.psx[l] = (R)10 + (A.p.rcx[l] - (R)10); A.psy[l] = (R)20 + (A.p.rcy[l] - (R)20);
             if (l < na) { // set_thrust (RR_Robot.py:100-102)
                 if (thrust) {
                     A.i.thl[l] = (int)m_rint(thrust[2 * l]); A.i.thr[l] = (int)m_rint(thrust[2 * l + 1]);
