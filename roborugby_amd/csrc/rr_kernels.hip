@@ -45,17 +45,26 @@ template <class C> __device__ __forceinline__ void store_record(const Arena<C> &
     for (int k = lane; k < Arena<C>::I_INTS; k += C::VW) irec[k] = q[k];
 }
 
+#ifndef RR_MIN_WAVES_PER_SIMD
+#define RR_MIN_WAVES_PER_SIMD 4 // upper bound of the occupancy asked from the register allocator (<=128 VGPRs)
+#endif
 #ifndef RR_WAVES_PER_BLOCK
 #define RR_WAVES_PER_BLOCK 1 // arenas never cooperate across wavefronts, so a workgroup IS a wavefront (finer dispatch: +9 % measured)
 #endif
 constexpr int WAVES_PER_BLOCK = RR_WAVES_PER_BLOCK;
 template <class C> constexpr int arenas_per_block() { return 64 * WAVES_PER_BLOCK / C::VW; }
-#ifndef RR_MIN_WAVES_PER_SIMD
-#define RR_MIN_WAVES_PER_SIMD 4 // <=128 VGPRs: 4 waves/SIMD measured 4x faster than the 1 wave/SIMD the allocator picks unconstrained
-#endif
+// Waves per SIMD the 160 KiB of LDS admit for this configuration.  Asking the register allocator for more than that
+// (launch bounds) only buys spills: with 17 KB of LDS per wavefront G/VW=8 and T/VW=2 top out at 2 waves/SIMD, and
+// capping them at 128 VGPRs put ~30 scratch round trips into every sub-step (measured: 487 VMEM instructions per
+// wave-step instead of ~90, and a 0.25 ms latency floor per launch).
+template <class C> constexpr int lds_waves_per_simd() {
+    constexpr int per_cu = (160 * 1024) / (int)(sizeof(Arena<C>) * arenas_per_block<C>()) * WAVES_PER_BLOCK;
+    return per_cu / 4 < 1 ? 1 : (per_cu / 4 > RR_MIN_WAVES_PER_SIMD ? RR_MIN_WAVES_PER_SIMD : per_cu / 4);
+}
+
 
 template <class C, typename O>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, RR_MIN_WAVES_PER_SIMD) void k_step(SimParams<typename C::Real> sp, typename C::Real *recs,
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void k_step(SimParams<typename C::Real> sp, typename C::Real *recs,
                                                               int32_t *irecs, int n, const int32_t *actions,
                                                               const float *thrust, int na, O *obs, O *reward,
                                                               uint8_t *done, O *obs_g, O *reward_g, int32_t *status) {
@@ -67,16 +76,26 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, RR_MIN_WAVES_PER_SIMD) void k
     typename C::Real *rec = recs + (size_t)arena * Arena<C>::P_STRIDE;
     int32_t *irec = irecs + (size_t)arena * Arena<C>::I_STRIDE;
     RR_T0();
+#if defined(RR_PROFILE_PHASES)
+    const unsigned long long rr_wave_t0_ = __builtin_amdgcn_s_memrealtime(); // 100 MHz, one base for the whole chip
+#endif
     load_record(A, rec, irec);
     derive(A, sp);
     RR_STAMP(12);
     StepOut<O> o = { obs + (size_t)arena * 11, obs_g ? obs_g + (size_t)arena * 11 : nullptr, reward + arena,
-                     reward_g ? reward_g + arena : nullptr, done + arena, status ? status + arena : nullptr };
+                     reward_g ? reward_g + arena : nullptr, done + arena, status ? status + arena : nullptr,
+                     sp.memo ? reinterpret_cast<uint32_t *>(rec) : nullptr, irec };
     step_arena<C, O>(A, sp, sp.arena_offset + (uint64_t)arena, actions ? actions + (size_t)arena * na : nullptr,
                      thrust ? thrust + (size_t)arena * 2 * na : nullptr, na, o);
     RR_TR();
     store_record(A, rec, irec);
     RR_STAMP(13);
+#if defined(RR_PROFILE_PHASES)
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 65536) {
+        g_rr_wave_t[2 * blockIdx.x] = rr_wave_t0_;
+        g_rr_wave_t[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // env.reset() for masked arenas; also used (init = 1) to build the constructor's state
@@ -242,11 +261,15 @@ __global__ void k_observe_kind(SimParams<typename C::Real> sp, const typename C:
 // ------------------------------------------------------------------------------------------------ host side
 // Built configurations: (kind = shape + 2*dtype, entity counts, Real, VW).  The first VW listed for a kind is the
 // default; the environment variable RR_VW selects another built width (kernel tuning / A-B runs).
+#ifdef RR_CFG_SUBSET // tuning builds only (tools/build_variant.sh): the two default configurations, quick to compile
+#define RR_FOR_EACH_CFG(X) X(0, 1, 0, 1, 0, double, 2) X(1, 2, 2, 4, 4, double, 8)
+#else
 #define RR_FOR_EACH_CFG(X)                                                                             \
     X(0, 1, 0, 1, 0, double, 2) X(0, 1, 0, 1, 0, double, 4) X(0, 1, 0, 1, 0, double, 8) X(0, 1, 0, 1, 0, double, 64) \
     X(1, 2, 2, 4, 4, double, 8) X(1, 2, 2, 4, 4, double, 16) X(1, 2, 2, 4, 4, double, 32) X(1, 2, 2, 4, 4, double, 64) \
     X(2, 1, 0, 1, 0, float, 2) X(2, 1, 0, 1, 0, float, 4) X(2, 1, 0, 1, 0, float, 64)                                 \
     X(3, 2, 2, 4, 4, float, 8) X(3, 2, 2, 4, 4, float, 16) X(3, 2, 2, 4, 4, float, 64)
+#endif
 
 struct rr_env {
     rr_config cfg;
@@ -283,6 +306,7 @@ template <typename R> static void fill_params(SimParams<R> &sp, const rr_config 
     sp.inner_cdist = (R)std::pow(hr * hr + hr * hr, .5);
     sp.game_len = c.game_len_steps; sp.game_mode = c.game_mode; sp.time_limit = c.time_limit; sp.auto_reset = c.auto_reset;
     sp.reset_on_fault = c.reset_on_fault;
+    { const char *nm = getenv("RR_NO_MEMO"); sp.memo = (nm && atoi(nm)) ? 0 : 1; } // fixed-point check of the sub-step loop (exact; the switch is for A/B runs)
     sp.seed = c.seed; sp.arena_offset = c.arena_offset;
 }
 template <typename R> static const SimParams<R> &params_of(const rr_env *e);
@@ -629,6 +653,11 @@ int rr_debug_phase_cycles(unsigned long long *host32, int clear) {
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_rr_prof), z, sizeof z) != hipSuccess) return -2;
     }
     return 0;
+}
+// diagnostic build only: [start, end] clock stamps of the first n wavefronts of the last k_step launch
+int rr_debug_wave_times(unsigned long long *host, int n) {
+    if (n > 65536) n = 65536;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rr_wave_t), (size_t)2 * n * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
 }
 #endif
 

@@ -20,6 +20,7 @@
 // noises listed in DESIGN.md.
 #pragma once
 #include <stdint.h>
+#include <stddef.h>
 #include <math.h>
 
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
@@ -67,10 +68,12 @@
 #define RR_VOTE(mask, l, pred) (mask) |= ((uint64_t)((pred) ? 1 : 0)) << (l)
 #endif
 
-// Diagnostic build only (-DRR_PROFILE_PHASES): per-phase cycle totals of wave-leader lanes, accumulated with atomics
-// into a device array that tools/phase_profile.py reads.  Never compiled into the product library.
+// Diagnostic build only (-DRR_PROFILE_PHASES): per-phase cycle totals of the leader lane of every 64th wavefront,
+// accumulated with atomics into a device array that tools/phase_profile.py reads (sampled: stamping every wave puts
+// ~600 k same-address atomics into each launch and measures mostly those).  Never compiled into the product library.
 #if defined(__HIPCC__) && defined(RR_PROFILE_PHASES)
 __device__ unsigned long long g_rr_prof[32];
+__device__ unsigned long long g_rr_wave_t[2 * 65536]; // [start, end] s_memtime of every wavefront of the last k_step launch
 #endif
 #if RR_GPU && defined(RR_PROFILE_PHASES)
 #define RR_T0() unsigned long long rr_t0_ = __builtin_amdgcn_s_memtime()
@@ -78,7 +81,7 @@ __device__ unsigned long long g_rr_prof[32];
 #define RR_STAMP(id)                                                                          \
     do {                                                                                      \
         unsigned long long rr_t1_ = __builtin_amdgcn_s_memtime();                             \
-        if ((threadIdx.x & 63) == 0) atomicAdd(&g_rr_prof[id], rr_t1_ - rr_t0_);              \
+        if ((threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 0) atomicAdd(&g_rr_prof[id], rr_t1_ - rr_t0_);              \
         rr_t0_ = rr_t1_;                                                                      \
     } while (0)
 #else
@@ -252,6 +255,7 @@ template <typename R> struct SimParams {
     R rob_cdist;                 // FloatRect._corner_dist of a 20x40 rect (MyUtils.py:138)
     R inner_h, inner_cdist;      // half side / corner dist of _rectBallInner (RR_TrashyPhysics.py:29-35)
     int32_t game_len, game_mode, time_limit, auto_reset, reset_on_fault;
+    int32_t memo;                // stop the sub-step loop at a bitwise fixed point (exact shortcut, see step_arena)
     uint64_t seed, arena_offset;
 };
 
@@ -261,7 +265,7 @@ RR_HD int side_a(int s) { return s == 0 ? TR : s == 1 ? TL : s == 2 ? BL : BR; }
 RR_HD int side_b(int s) { return s == 0 ? BR : s == 1 ? TR : s == 2 ? TL : BL; }
 
 // ------------------------------------------------------------------------------------------------ arena (LDS image)
-template <class C> struct Arena {
+template <class C> struct ArenaBody {
     using R = typename C::Real;
     static constexpr int NR = C::NR, NB = C::NB;
     // ---- persistent: identical order to the HBM record (field-major = SoA over the entities)
@@ -289,14 +293,30 @@ template <class C> struct Arena {
         R lidar[2][3 * NR];               // [front|back][ray, rect] minima over the rect's four sides
     } u;
     R lid[6];                             // capped minima: front/back per ray
-#ifdef RR_LDS_PAD
-    R pad_[NR > 1 ? RR_LDS_PAD : 1]; // occupancy experiments only
-#endif
     static constexpr int P_REALS = (int)(sizeof(P) / sizeof(R));
     static constexpr int I_INTS = (int)(sizeof(I) / sizeof(int32_t));
-    static constexpr int P_STRIDE = (P_REALS + 15) / 16 * 16; // record strides in HBM (128-B multiples)
+    static constexpr int P_STRIDE = (P_REALS + 3 * NR + 15) / 16 * 16; // record strides in HBM (128-B multiples; room for the fixed-point snapshot)
     static constexpr int I_STRIDE = (I_INTS + 15) / 16 * 16;
 };
+// LDS bank spreading.  The 64/VW arenas of a wavefront sit in consecutive LDS slices and their lanes touch the SAME
+// field at the same time, so the slice stride decides the banking: lane-strided accesses of one arena cover
+// win = VW * (words per Real) consecutive banks, and the arenas sharing a bank group (32 lanes for ds_read_b32/b64 with
+// 32/64 banks, 16 lanes for ds_write_b64 / ds_read2_b64 with 32 banks: MI355X_MICROARCH.md, LDS) tile the banks exactly
+// when stride = win * (odd number).  G/fp64/VW=8 was 576 words = 9 * 64: every arena on the same banks, 4-way
+// conflicts on every access (SQ_LDS_BANK_CONFLICT = 4x the LDS instruction cycles).  VW >= 32: one arena per group.
+constexpr int lds_pad_words(int body_words, int vw, int real_words) {
+#ifdef RR_NO_LDS_PAD // A/B builds only
+    return 0;
+#endif
+    if (vw >= 32) return 0;
+    const int win = vw * real_words;
+    int pad = (win - body_words % win) % win;
+    if (((body_words + pad) / win) % 2 == 0) pad += win;
+    return pad;
+}
+template <class C, int PAD> struct ArenaPadded : ArenaBody<C> { uint32_t lds_pad_[PAD]; };
+template <class C> struct ArenaPadded<C, 0> : ArenaBody<C> {};
+template <class C> using Arena = ArenaPadded<C, lds_pad_words((int)(sizeof(ArenaBody<C>) / 4), C::VW, (int)(sizeof(typename C::Real) / 4))>;
 
 // ------------------------------------------------------------------------------------------------ FloatRect in registers
 template <typename R> struct FR {
@@ -487,6 +507,22 @@ template <class C> RR_HD void ensure_sides(Arena<C> &A) {
 template <typename R> RR_HD R cull_rr2() { return (R)(45.5 * 45.5); }
 template <typename R> RR_HD R cull_br2() { return (R)(33.0 * 33.0); }
 
+// Second, tighter exact bound in the robot's own frame.  ball_robot_collided hits only if a robot corner is within 7 of
+// the ball centre or one of the two diameters -- 14 long, centred on the ball, parallel / perpendicular to the robot's
+// sides -- really crosses a side segment (an intersection point inside the bounding boxes of both segments lies on
+// both segments).  Either way the ball centre is within 7 of the 20 x 40 rectangle along each robot axis:
+// |x_local| <= 10 + 7, |y_local| <= 20 + 7.  The axes come from the corner offsets (unit to ~1e-15); 0.05 px of slack.
+template <class C> RR_HD bool ball_near_robot(const Arena<C> &A, int b, int r) {
+    using R = typename C::Real;
+    const R dx = A.p.bcx[b] - A.p.rcx[r], dy = A.p.bcy[b] - A.p.rcy[r];
+    if (!(dx * dx + dy * dy <= cull_br2<R>())) return false;
+    const R *q = A.rel[r];
+    const R ux = (q[2] - q[0]) * (R)0.05, uy = (q[3] - q[1]) * (R)0.05;     // TL -> TR, 20 long
+    const R vx = (q[4] - q[0]) * (R)0.025, vy = (q[5] - q[1]) * (R)0.025;   // TL -> BL, 40 long
+    const R lx = dx * ux + dy * uy, ly = dx * vx + dy * vy;
+    return (m_abs(lx) <= (R)17.05) & (m_abs(ly) <= (R)27.05);
+}
+
 // ------------------------------------------------------------------------------------------------ contact predicates, one task per lane
 // robots_collided (RR_TrashyPhysics.py:18-24): task = (pair, side of bot1, side of bot2)
 template <class C> RR_HD void pair_of(int p, int n, int &i, int &j) { // p-th (i<j) pair in nested-loop order
@@ -547,16 +583,13 @@ template <class C> RR_HD uint32_t detect_robot_pairs(Arena<C> &A) {
 // corners against the radius and its diameter against the four sides.  Bit (b*NR + r) of the result.
 template <class C> RR_HD uint32_t detect_ball_robot(Arena<C> &A, const SimParams<typename C::Real> &sp) {
     using R = typename C::Real;
-    // broad phase: one lane per ball sweeps the robots and publishes its NR-bit mask
+    // broad phase: one lane per ball sweeps the robots (radius bound, then the robot-frame bound) and publishes its mask
     uint64_t anyc = 0;
     RR_FOR_LANES(l) {
         bool c = false;
         if (l < C::NB) {
             int msk = 0;
-            for (int r = 0; r < C::NR; r++) {
-                R dx = A.p.bcx[l] - A.p.rcx[r], dy = A.p.bcy[l] - A.p.rcy[r];
-                msk |= (dx * dx + dy * dy <= cull_br2<R>()) ? (1 << r) : 0;
-            }
+            for (int r = 0; r < C::NR; r++) msk |= ball_near_robot(A, l, r) ? (1 << r) : 0;
             A.brc[l] = msk;
             c = msk != 0;
         }
@@ -566,13 +599,8 @@ template <class C> RR_HD uint32_t detect_ball_robot(Arena<C> &A, const SimParams
     RR_SYNC();
     uint32_t close = 0;
     for (int b = 0; b < C::NB; b++) close |= (uint32_t)A.brc[b] << (b * C::NR);
-    if (!close) return 0;
-    // narrow phase: the inner-square corner offsets (rot+45) are only needed now
-    RR_FOR_LANES(l) {
-        if (l < C::NR) refresh_inner_lane(A, sp, l);
-    }
-    RR_SYNC();
-    ensure_sides(A);
+    // narrow phase, one lane per (close pair, diameter), everything it needs computed in the lane (no further phases):
+    // the inner square's corner offsets for rot+45 (RR_TrashyPhysics.py:54-55) and the four side slopes
     uint32_t pairs = 0;
     constexpr int NT = C::NB * C::NR * 2; // task = (pair, diameter)
     for (int base = 0; base < NT; base += C::VW) {
@@ -586,15 +614,18 @@ template <class C> RR_HD uint32_t detect_ball_robot(Arena<C> &A, const SimParams
                 int d = t & 1, pr = t >> 1, r = pr % C::NR, b = pr / C::NR, st = 0;
                 V2<R> bc = { A.p.bcx[b], A.p.bcy[b] };
                 hit = (dist<R>(robot_corner(A, r, 2 * d), bc) < (R)7) | (dist<R>(robot_corner(A, r, 2 * d + 1), bc) < (R)7);
+                R iq[8];
+                corners_for<R>(py_mod<R>(A.p.rrot[r] + (R)45 + (R)720, (R)360), sp.inner_h, sp.inner_h, sp.inner_cdist, iq);
                 // diameters (TL->BR) and (TR->BL) of the inner square
                 int ca = d == 0 ? TL : TR, cb = d == 0 ? BR : BL;
-                Seg<R> dia = { { bc.x + A.u.irel[r][2 * ca], bc.y + A.u.irel[r][2 * ca + 1] },
-                               { bc.x + A.u.irel[r][2 * cb], bc.y + A.u.irel[r][2 * cb + 1] } };
+                Seg<R> dia = { { bc.x + iq[2 * ca], bc.y + iq[2 * ca + 1] }, { bc.x + iq[2 * cb], bc.y + iq[2 * cb + 1] } };
                 R md, cd;
                 slope_yint<R>(dia.a, dia.b, md, cd, st);
                 for (int sd = 0; sd < 4; sd++) {
                     Seg<R> side = robot_side(A, r, sd);
-                    V2<R> q = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, md, cd, dia.a.x);
+                    R ms, cs;
+                    slope_yint<R>(side.a, side.b, ms, cs, st);
+                    V2<R> q = intersect_mb<R>(ms, cs, side.a.x, md, cd, dia.a.x);
                     hit = hit | (within<R>(q, side, (R)0) & within<R>(q, dia, (R)0));
                 }
             }
@@ -602,6 +633,13 @@ template <class C> RR_HD uint32_t detect_ball_robot(Arena<C> &A, const SimParams
         }
         for (int q = 0; q < C::VW / 2; q++)
             if ((m >> (2 * q)) & 3ull) pairs |= 1u << ((base >> 1) + q);
+    }
+    if (pairs) { // rare: the responses read the cached inner-square offsets and side slopes
+        RR_FOR_LANES(l) {
+            if (l < C::NR) refresh_inner_lane(A, sp, l);
+        }
+        RR_SYNC();
+        ensure_sides(A);
     }
     return pairs;
 }
@@ -923,12 +961,13 @@ template <class C> RR_HD void ball_undo_lane(Arena<C> &A, int b) {
 }
 
 // ------------------------------------------------------------------------------------------------ sub-step pieces (RR_EnvBase.py:303-454)
-template <class C> RR_HDN void resolve_bot_collisions(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &bots_moved, uint32_t &naughty, int &st) {
+template <class C> RR_HDN void resolve_bot_collisions(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &bots_moved, uint32_t &naughty, int &st, int &work) {
     if (C::NPR == 0) return;
     uint32_t pairs = detect_robot_pairs(A);
     int attempts = 0;
     while (pairs) {
         attempts++;
+        work += 4;
         if (attempts > C::NR) { st |= ST_BOT_RESOLVE_FAIL; return; }
 #pragma unroll 1
         for (int p = 0; p < C::NPR; p++) {
@@ -949,11 +988,12 @@ template <class C> RR_HDN void resolve_bot_collisions(Arena<C> &A, const SimPara
         pairs = detect_robot_pairs(A);
     }
 }
-template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t bots_moved, int &st) {
+template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t bots_moved, int &st, int &work) {
     bool naughty = true;
     int count = 0;
     while (naughty) {
         count++;
+        work++;
         if (count > 10) return false;
         naughty = false;
         uint64_t bb = detect_ball_pairs(A);
@@ -1040,8 +1080,9 @@ RR_HDN void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real>
 // [robot-robot + ball-robot broad phase], [roll], [ball-ball + ball-robot broad phase + wall test].  Only when a
 // ballot reports something close do the reference-shaped loops below (unchanged, exact) run.
 // `prev_moved`: robots whose move of the previous sub-step survived (their ring entry moveCount-1 is that frame's).
+// `work`: += the contact-resolution passes this sub-step ran (0 on the common path); feeds the fixed-point check below.
 template <class C>
-RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &naughty, int &st, uint32_t &prev_moved) {
+RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &naughty, int &st, uint32_t &prev_moved, int &work) {
     using R = typename C::Real;
     uint32_t bots_moved = (1u << C::NR) - 1, balls_moved = (1u << C::NB) - 1;
     RR_TRACE("E substep\n");
@@ -1077,7 +1118,7 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     RR_SYNC();
     RR_STAMP(1);
     if (m_rr) {
-        resolve_bot_collisions(A, sp, bots_moved, naughty, st);
+        resolve_bot_collisions(A, sp, bots_moved, naughty, st, work);
         m_br = 1; // an undone robot changes the ball-robot picture: let the full detection decide
     }
     RR_STAMP(2);
@@ -1108,10 +1149,7 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
                 R reach = (R)14.04 + tr;
                 c = c | ((j != l) & (dx * dx + dy * dy <= reach * reach));
             }
-            for (int r = 0; r < C::NR; r++) {
-                R dx = mx - A.p.rcx[r], dy = my - A.p.rcy[r];
-                c = c | (dx * dx + dy * dy <= cull_br2<R>());
-            }
+            for (int r = 0; r < C::NR; r++) c = c | ball_near_robot(A, l, r);
             c = c | ball_collided_wall(A, sp, l);
         }
         RR_VOTE(m_any, l, c);
@@ -1119,9 +1157,9 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     RR_SYNC();
     RR_STAMP(4);
     if (m_any) { // the reference's loop, from its first pass (nothing has changed since the broad phase above)
-        bool rr_ok_ = resolve_ball_collisions(A, sp, bots_moved, st);
+        bool rr_ok_ = resolve_ball_collisions(A, sp, bots_moved, st, work);
         RR_STAMP(5);
-        if (!rr_ok_) undo_naughty_movement(A, sp, balls_moved, bots_moved, st);
+        if (!rr_ok_) { work += 8; undo_naughty_movement(A, sp, balls_moved, bots_moved, st); }
     }
     RR_STAMP(6);
     prev_moved = bots_moved;
@@ -1363,7 +1401,57 @@ template <typename O> struct StepOut {
     O *obs, *obs_g, *reward, *reward_g;
     uint8_t *done;
     int32_t *status;
+    uint32_t *snap = nullptr;  // >= sizeof(Arena::P)/4 words of scratch for the fixed-point check (the arena's HBM record), or null
+    int32_t *isnap = nullptr;  // >= NR words
 };
+
+// Fixed point of the sub-step map.  A stuck arena -- a ball squeezed between two robots, a robot pushing a ball into
+// a wall -- runs the push, all 10 resolve passes and the undo loop in every sub-step, and the undo puts everything
+// back: the sub-step maps the state onto itself, 12 times per step, at ~150x the cost of a quiet sub-step (one such
+// arena used to set the duration of a whole 65,536-arena launch).  A sub-step is a deterministic function of the
+// persistent state (the P record and the move counters), the thrust (fixed during a step), `prev_moved` and the
+// frame-begin poses ax/ay/arot of the robots in it (the pose-ring update at the top of the next sub-step reads them);
+// so if all of that after sub-step k is bit-identical to what it was after sub-step k-1, sub-step k+1 gets the very
+// input sub-step k got, and by induction every later sub-step of this step reproduces the same state (and ORs the
+// same bits into `naughty` / `st`): the loop can stop.  Exact, not approximate.
+// The comparison is bitwise (NaN-safe), lane-strided, against a snapshot kept in the arena's own HBM record (dead
+// between load_record and store_record); it is only made after sub-steps that ran the expensive contact paths.
+// cheap necessary condition, from LDS only: every robot ends the sub-step on its frame-begin pose (undone, blocked or idle)
+template <class C> RR_HD bool robots_unmoved(const Arena<C> &A) {
+    uint64_t any_moved = 0;
+    RR_FOR_LANES(l) {
+        const bool mv = (l < C::NR) && !(A.p.rcx[l] == A.ax[l] && A.p.rcy[l] == A.ay[l] && A.p.rrot[l] == A.arot[l]);
+        RR_VOTE(any_moved, l, mv);
+    }
+    return !any_moved;
+}
+template <class C> RR_HD bool snapshot_same_and_update(const Arena<C> &A, uint32_t *snap, int32_t *isnap, bool have) {
+    using R = typename C::Real;
+    constexpr int NW = (int)(sizeof(typename Arena<C>::P) / 4);   // the persistent reals ...
+    constexpr int NA = (int)(3 * C::NR * sizeof(R) / 4);          // ... + ax, ay, arot: the frame-begin poses the next sub-step's ring update reads
+    static_assert(Arena<C>::P_STRIDE * sizeof(R) / 4 >= (size_t)(NW + NA), "the HBM record holds the snapshot");
+    static_assert(offsetof(ArenaBody<C>, ay) == offsetof(ArenaBody<C>, ax) + C::NR * sizeof(R) &&
+                  offsetof(ArenaBody<C>, arot) == offsetof(ArenaBody<C>, ax) + 2 * C::NR * sizeof(R), "ax, ay, arot are contiguous");
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(&A.p);
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(&A.ax[0]);
+    uint64_t any_diff = 0;
+    RR_FOR_LANES(l) {
+        bool diff = false;
+        for (int k = l; k < NW + NA; k += C::VW) {
+            const uint32_t v = k < NW ? p[k] : q[k - NW];
+            if (have) diff = diff | (snap[k] != v);
+            if (have && snap[k] != v) RR_TRACE("E   snapshot word %d differs\n", k);
+            snap[k] = v;
+        }
+        for (int k = l; k < C::NR; k += C::VW) {
+            const int32_t v = A.i.mc[k];
+            if (have) diff = diff | (isnap[k] != v);
+            isnap[k] = v;
+        }
+        RR_VOTE(any_diff, l, diff);
+    }
+    return have && !any_diff;
+}
 
 // actions: this arena's na discrete actions (thrust == nullptr) or 2*na thrust floats
 template <class C, typename O>
@@ -1439,9 +1527,18 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     RR_SYNC();
     uint32_t naughty = 0;
     RR_STAMP(8);
-    uint32_t prev_moved = 0;
+    uint32_t prev_moved = 0, snap_moved = 0;
+    int snap_at = -2; // sub-step whose end state the snapshot holds
 #pragma unroll 1
-    for (int f = 0; f < RR_NUM_SUBSTEPS; f++) substep(A, sp, naughty, st, prev_moved); // MOVES_PER_FRAME
+    for (int f = 0; f < RR_NUM_SUBSTEPS; f++) { // MOVES_PER_FRAME
+        int work = 0;
+        substep(A, sp, naughty, st, prev_moved, work);
+        if (o.snap && work >= 3 && f + 1 < RR_NUM_SUBSTEPS && robots_unmoved(A)) { // expensive sub-step: has the arena stopped changing?
+            const bool same = snapshot_same_and_update(A, o.snap, o.isnap, snap_at == f - 1) && snap_moved == prev_moved;
+            if (same) { RR_TRACE("E fixed point after sub-step %d\n", f); break; } // sub-steps f+1.. would reproduce this state bit for bit
+            snap_at = f; snap_moved = prev_moved;
+        }
+    }
     substeps_end(A, prev_moved);
     RR_STAMP(9);
     // ---- on_step_end: NaughtyBots, ChasePosBall, PushPosBallsToGoal (SURVEY 3.1 accumulation order)

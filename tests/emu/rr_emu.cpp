@@ -4,6 +4,7 @@
 // oracle without a GPU.  The product library never links or loads this.
 static int g_dbg_substeps = 12;
 static int g_dbg_trace = 0;
+static int g_dbg_memo = 1; // fixed-point check of the sub-step loop on/off (tests compare both)
 #define RR_NUM_SUBSTEPS g_dbg_substeps
 #define RR_EMU_TRACE g_dbg_trace
 #include "../../roborugby_amd/csrc/rr_sim.hpp"
@@ -19,6 +20,8 @@ template <class C> struct Emu {
     SimParams<typename C::Real> sp;
     Program prog;     // reward keepers in execution order (default = SimpleDuel3)
     bool custom_prog;
+    uint32_t snap[Arena<C>::P_STRIDE * sizeof(typename C::Real) / 4];
+    int32_t isnap[C::NR];
 };
 
 template <typename R> static void fill_params(SimParams<R> &sp, double W, double H, int game_len, int game_mode,
@@ -32,7 +35,7 @@ template <typename R> static void fill_params(SimParams<R> &sp, double W, double
     sp.inner_cdist = (R)std::pow(hr * hr + hr * hr, .5);
     sp.game_len = game_len; sp.game_mode = game_mode; sp.time_limit = time_limit; sp.auto_reset = auto_reset & 1;
     sp.reset_on_fault = (auto_reset >> 1) & 1; // bit 1 of the flag word
-    sp.seed = seed; sp.arena_offset = 0;
+    sp.seed = seed; sp.arena_offset = 0; sp.memo = 1;
 }
 
 template <class C> static void set_state(Emu<C> *e, const double *robots, const int32_t *ri, const double *balls, int step) {
@@ -92,6 +95,7 @@ struct Handle { int kind; void *p; };
 extern "C" {
 void emu_debug_set_substeps(int k) { g_dbg_substeps = k; }
 void emu_debug_trace(int on) { g_dbg_trace = on; }
+void emu_debug_memo(int on) { g_dbg_memo = on; }
 // preset: 0 = T, 1 = G ; f32: 0/1 ; f32 == 2 selects the narrow-virtual-wave fp64 build
 Handle *emu_create(int preset, int f32, double W, double H, int game_len, int game_mode, int time_limit, int auto_reset,
                    uint64_t seed) {
@@ -137,7 +141,7 @@ template <class CC> static int emu_step_t(Emu<CC> *e, const int32_t *actions, co
     RR xs[3 * CC::NR + 1];
     Rec<CC> q = { reinterpret_cast<const RR *>(&e->A.p) };
     if (e->custom_prog) extras_begin<CC>(q, xs);
-    StepOut<double> o = { obs, obs_g, reward, reward_g, done, &status };
+    StepOut<double> o = { obs, obs_g, reward, reward_g, done, &status, g_dbg_memo ? e->snap : nullptr, e->isnap };
     step_arena<CC, double>(e->A, e->sp, 0, actions, thrust, na, o);
     if (e->custom_prog && !(status & (ST_WAS_RESET | ST_STEP_AFTER_DONE)))
         extras_end<CC, double>(q, e->sp, xs, e->prog, (uint32_t)status >> 16, reward, reward_g, &status);

@@ -30,11 +30,11 @@ torch.cuda.synchronize(); lib.rr_debug_phase_cycles(buf, 1)
 K = 20
 for _ in range(K): step()
 torch.cuda.synchronize(); lib.rr_debug_phase_cycles(buf, 0)
-names = ["(unused)", "frame hooks + move_bots", "rr+br broad phase, K1", "push (br detect+resp)", "roll", "resolve loop", "undo", "(unused)",
+names = ["(unused)", "hooks + moves + broad", "resolve_bot (if close)", "push (if close)", "roll + broad", "resolve loop (if close)", "undo (if failed)", "(unused)",
          "step_begin", "(12 substeps total)", "rewards", "obs+out", "load+derive", "store"]
 v = list(buf)[:14]
 tot = sum(v[i] for i in (8, 9, 10, 11, 12, 13))
-waves = n // (64 // env.lanes_per_env())
-print(f"{preset} {mode}: VW={env.lanes_per_env()} cycles(100MHz ticks?) per wave per step: {tot / K / waves:.0f}")
+waves = (n // (64 // env.lanes_per_env()) + 63) // 64  # every 64th wavefront is stamped
+print(f"{preset} {mode}: VW={env.lanes_per_env()} s_memtime ticks per wave per step: {tot / K / waves:.0f}")
 for i, nm in enumerate(names):
     print(f"  {nm:26s} {v[i] / K / waves:10.0f}  {100.0 * v[i] / tot:5.1f}%")
