@@ -176,8 +176,36 @@ template <typename R> RR_HD R py_mod(R a, R b) {                                
     }
     return m;
 }
+// Every float % on this path is `x % 360` with |x| of a few thousand at most.  fmod's result is exact, so it can be had
+// without libm's iterative reduction: q = floor(x / 360) up to one unit (the quotient comes from a rounded reciprocal
+// product), r = x - q * 360 in ONE rounding (fma; the true remainder is representable, so that rounding is exact),
+// and the off-by-one cases fixed by adding / subtracting 360 -- exact again for the same reason.  Bit-identical to
+// Python's % (checked against fmod on 2e8 values incl. the neighbours of every multiple of 360).  Domain: |x| < 2^40.
+template <> RR_HD double py_mod<double>(double a, double b) {
+    if (b != 360.0) {
+        double m = m_fmod(a, b);
+        if (m != 0.0) { if ((b < 0.0) != (m < 0.0)) m += b; } else m = 0.0;
+        return m;
+    }
+    double r;
+    if (a >= 0.0) {
+        const double q = ::floor(a * 2.77777777777777788e-03);
+        r = ::fma(-q, 360.0, a);
+        r = (r < 0.0) ? r + 360.0 : ((r >= 360.0) ? r - 360.0 : r);
+    } else { // never on the step path (angles are normalised before they get here); a correctly rounded quotient can
+             // only be one too large, and then r + 360 is Python's own single rounding (a tiny negative x gives 360.0)
+        const double q = ::floor(a / 360.0);
+        r = ::fma(-q, 360.0, a);
+        r = (r < 0.0) ? r + 360.0 : r;
+    }
+    return r == 0.0 ? 0.0 : r;
+}
 template <typename R> RR_HD R py_max(R a, R b) { return (b > a) ? b : a; } // first maximal wins
 template <typename R> RR_HD R py_min(R a, R b) { return (b < a) ? b : a; }
+
+// lowest set bit first: walks a hit mask in the reference's list order without visiting the empty positions
+RR_HD int low_bit(uint32_t m) { return __builtin_ctz(m); }
+RR_HD int low_bit(uint64_t m) { return __builtin_ctzll(m); }
 
 template <typename R> struct V2 { R x, y; };
 template <typename R> struct Seg { V2<R> a, b; };
@@ -293,6 +321,9 @@ template <class C> struct ArenaBody {
         R lidar[2][3 * NR];               // [front|back][ray, rect] minima over the rect's four sides
     } u;
     R lid[6];                             // capped minima: front/back per ray
+#ifdef RR_LDS_EXTRA
+    R extra_[NR > 1 ? RR_LDS_EXTRA : 1]; // occupancy experiments only
+#endif
     static constexpr int P_REALS = (int)(sizeof(P) / sizeof(R));
     static constexpr int I_INTS = (int)(sizeof(I) / sizeof(int32_t));
     static constexpr int P_STRIDE = (P_REALS + 3 * NR + 15) / 16 * 16; // record strides in HBM (128-B multiples; room for the fixed-point snapshot)
@@ -555,8 +586,8 @@ template <class C> RR_HD uint32_t detect_robot_pairs(Arena<C> &A) {
     // narrow phase: the 16 (side, side) tests of each close pair, VW of them per round
     uint32_t pairs = 0;
 #pragma unroll 1
-    for (int p = 0; p < C::NPR; p++) {
-        if (!(close & (1u << p))) continue;
+    for (uint32_t todo = close; todo; todo &= todo - 1) {
+        const int p = low_bit(todo);
         int i, j;
         pair_of<C>(p, C::NR, i, j);
         uint64_t any = 0;
@@ -581,7 +612,12 @@ template <class C> RR_HD uint32_t detect_robot_pairs(Arena<C> &A) {
 }
 // ball_robot_collided (RR_TrashyPhysics.py:39-69): task = (ball, robot, diameter); each lane tests two
 // corners against the radius and its diameter against the four sides.  Bit (b*NR + r) of the result.
-template <class C> RR_HD uint32_t detect_ball_robot(Arena<C> &A, const SimParams<typename C::Real> &sp) {
+// CACHED = false (the first sweep of a sub-step, usually the only one): a lane computes everything it needs itself --
+// the inner square's corner offsets for rot+45 (RR_TrashyPhysics.py:54-55) and the four side slopes -- so a quiet
+// sub-step pays no cache-building phases.  CACHED = true (the later passes of the resolve / undo loops, where the
+// robots stand still): the robot-only operands come from the LDS caches (irel keyed by rotation, sm/sc by pose), which
+// leaves the diameter's own slope and the four intersections.  Same operands, same operations, same results.
+template <class C, bool CACHED> RR_HD uint32_t detect_ball_robot(Arena<C> &A, const SimParams<typename C::Real> &sp) {
     using R = typename C::Real;
     // broad phase: one lane per ball sweeps the robots (radius bound, then the robot-frame bound) and publishes its mask
     uint64_t anyc = 0;
@@ -599,8 +635,13 @@ template <class C> RR_HD uint32_t detect_ball_robot(Arena<C> &A, const SimParams
     RR_SYNC();
     uint32_t close = 0;
     for (int b = 0; b < C::NB; b++) close |= (uint32_t)A.brc[b] << (b * C::NR);
-    // narrow phase, one lane per (close pair, diameter), everything it needs computed in the lane (no further phases):
-    // the inner square's corner offsets for rot+45 (RR_TrashyPhysics.py:54-55) and the four side slopes
+    if (CACHED) {
+        RR_FOR_LANES(l) {
+            if (l < C::NR) refresh_inner_lane(A, sp, l); // no-op while the rotation stands
+        }
+        RR_SYNC();
+        ensure_sides(A);
+    }
     uint32_t pairs = 0;
     constexpr int NT = C::NB * C::NR * 2; // task = (pair, diameter)
     for (int base = 0; base < NT; base += C::VW) {
@@ -614,17 +655,23 @@ template <class C> RR_HD uint32_t detect_ball_robot(Arena<C> &A, const SimParams
                 int d = t & 1, pr = t >> 1, r = pr % C::NR, b = pr / C::NR, st = 0;
                 V2<R> bc = { A.p.bcx[b], A.p.bcy[b] };
                 hit = (dist<R>(robot_corner(A, r, 2 * d), bc) < (R)7) | (dist<R>(robot_corner(A, r, 2 * d + 1), bc) < (R)7);
-                R iq[8];
-                corners_for<R>(py_mod<R>(A.p.rrot[r] + (R)45 + (R)720, (R)360), sp.inner_h, sp.inner_h, sp.inner_cdist, iq);
-                // diameters (TL->BR) and (TR->BL) of the inner square
-                int ca = d == 0 ? TL : TR, cb = d == 0 ? BR : BL;
-                Seg<R> dia = { { bc.x + iq[2 * ca], bc.y + iq[2 * ca + 1] }, { bc.x + iq[2 * cb], bc.y + iq[2 * cb + 1] } };
+                // diameters (TL->BR) for d = 0 and (TR->BL) for d = 1 of the inner square; BR = -TL, BL = -TR
+                R ox, oy;
+                if (CACHED) {
+                    ox = A.u.irel[r][2 * d]; oy = A.u.irel[r][2 * d + 1];
+                } else {
+                    R iq[8];
+                    corners_for<R>(py_mod<R>(A.p.rrot[r] + (R)45 + (R)720, (R)360), sp.inner_h, sp.inner_h, sp.inner_cdist, iq);
+                    ox = d == 0 ? iq[0] : iq[2]; oy = d == 0 ? iq[1] : iq[3];
+                }
+                Seg<R> dia = { { bc.x + ox, bc.y + oy }, { bc.x + -ox, bc.y + -oy } };
                 R md, cd;
                 slope_yint<R>(dia.a, dia.b, md, cd, st);
                 for (int sd = 0; sd < 4; sd++) {
                     Seg<R> side = robot_side(A, r, sd);
                     R ms, cs;
-                    slope_yint<R>(side.a, side.b, ms, cs, st);
+                    if (CACHED) { ms = A.sm[r][sd]; cs = A.sc[r][sd]; }
+                    else slope_yint<R>(side.a, side.b, ms, cs, st);
                     V2<R> q = intersect_mb<R>(ms, cs, side.a.x, md, cd, dia.a.x);
                     hit = hit | (within<R>(q, side, (R)0) & within<R>(q, dia, (R)0));
                 }
@@ -634,7 +681,7 @@ template <class C> RR_HD uint32_t detect_ball_robot(Arena<C> &A, const SimParams
         for (int q = 0; q < C::VW / 2; q++)
             if ((m >> (2 * q)) & 3ull) pairs |= 1u << ((base >> 1) + q);
     }
-    if (pairs) { // rare: the responses read the cached inner-square offsets and side slopes
+    if (pairs && !CACHED) { // rare: the responses read the cached inner-square offsets and side slopes
         RR_FOR_LANES(l) {
             if (l < C::NR) refresh_inner_lane(A, sp, l);
         }
@@ -693,23 +740,45 @@ template <class C> RR_HD uint32_t detect_ball_wall(const Arena<C> &A, const SimP
 // rectDblPriorFrame (RR_Robot.py:43-58): pose at the start of the robot's last move that was not undone.  Only the
 // (rare) contact responses need its corners, so they are rebuilt here on demand exactly like the reference does
 // (`rectPrior.rotation = rot` re-runs the rotation setter on (rot+720)%360).
+template <typename R> struct PrevPose { R x, y, tlx, tly, trx, try_; }; // prior centre + TL / TR corner offsets (BR = -TL, BL = -TR)
 template <class C>
-RR_HD void robot_prev_frame(const Arena<C> &A, const SimParams<typename C::Real> &sp, int r, uint32_t bots_moved,
-                            typename C::Real &x, typename C::Real &y, typename C::Real *rel) {
+RR_HD PrevPose<typename C::Real> robot_prev_frame(const Arena<C> &A, const SimParams<typename C::Real> &sp, int r, uint32_t bots_moved) {
     using R = typename C::Real;
+    PrevPose<R> q;
     // rectPrior = rectDbl.copy(): centre c' = 10 + (cx - 10); then `rectPrior.center = (x, y)` moves it by (x - c')
     const R ccx = (R)10 + (A.p.rcx[r] - (R)10), ccy = (R)20 + (A.p.rcy[r] - (R)20);
     R rot;
-    if (bots_moved & (1u << r)) { x = ccx + (A.ax[r] - ccx); y = ccy + (A.ay[r] - ccy); rot = A.arot[r]; }
-    else if (!is_nan(A.p.px[r])) { x = ccx + (A.p.px[r] - ccx); y = ccy + (A.p.py[r] - ccy); rot = A.p.prot[r]; }
-    else { x = ccx; y = ccy; rot = A.p.rrot[r]; }
-    corners_for<R>(py_mod<R>(rot + (R)720, (R)360), (R)10, (R)20, sp.rob_cdist, rel);
+    if (bots_moved & (1u << r)) { q.x = ccx + (A.ax[r] - ccx); q.y = ccy + (A.ay[r] - ccy); rot = A.arot[r]; }
+    else if (!is_nan(A.p.px[r])) { q.x = ccx + (A.p.px[r] - ccx); q.y = ccy + (A.p.py[r] - ccy); rot = A.p.prot[r]; }
+    else { q.x = ccx; q.y = ccy; rot = A.p.rrot[r]; }
+    const R nr = py_mod<R>(rot + (R)720, (R)360);
+    if (nr == A.p.rrot[r]) {
+        // same rotation value as the live rect (a robot driving straight, or one that has not turned since): the setter
+        // returns early and the copy keeps the live corners -- which ARE corners_for(rrot): every writer of A.rel builds
+        // it with that very expression -- so no trigonometry here.  The common case of a robot pushing a ball.
+        q.tlx = A.rel[r][0]; q.tly = A.rel[r][1]; q.trx = A.rel[r][2]; q.try_ = A.rel[r][3];
+    } else {
+        R rel[8];
+        corners_for<R>(nr, (R)10, (R)20, sp.rob_cdist, rel);
+        q.tlx = rel[0]; q.tly = rel[1]; q.trx = rel[2]; q.try_ = rel[3];
+    }
+    return q;
+}
+template <typename R> RR_HD V2<R> prev_corner(const PrevPose<R> &q, int c) { // TL, TR, BL = -TR, BR = -TL
+    const R ox = (c == TL) ? q.tlx : (c == TR) ? q.trx : (c == BL) ? -q.trx : -q.tlx;
+    const R oy = (c == TL) ? q.tly : (c == TR) ? q.try_ : (c == BL) ? -q.try_ : -q.tly;
+    V2<R> v = { q.x + ox, q.y + oy };
+    return v;
 }
 template <class C> RR_HD void force_diameters(const Arena<C> &A, int r, V2<typename C::Real> bc, Seg<typename C::Real> dia[2]) {
     // (BL->TR) and (BR->TL), RR_TrashyPhysics.py:95-104
     const typename C::Real *q = A.u.irel[r];
     dia[0].a = { bc.x + q[2 * BL], bc.y + q[2 * BL + 1] }; dia[0].b = { bc.x + q[2 * TR], bc.y + q[2 * TR + 1] };
     dia[1].a = { bc.x + q[2 * BR], bc.y + q[2 * BR + 1] }; dia[1].b = { bc.x + q[2 * TL], bc.y + q[2 * TL + 1] };
+}
+template <typename R> RR_HD Seg<R> pick_dia(const Seg<R> dia[2], int d) { // by value: no dynamically indexed local array
+    Seg<R> g = { { d ? dia[1].a.x : dia[0].a.x, d ? dia[1].a.y : dia[0].a.y }, { d ? dia[1].b.x : dia[0].b.x, d ? dia[1].b.y : dia[0].b.y } };
+    return g;
 }
 // First (side, diameter) candidate -- sides in RIGHT,TOP,LEFT,BOTTOM order, diameters (BL->TR) then (BR->TL) -- whose
 // intersection lies within the side and within the diameter grown by `buf`: the surface-contact search shared by
@@ -729,19 +798,17 @@ RR_HD int first_surface_hit(Arena<C> &A, int r, const Seg<typename C::Real> dia[
                 const int sd = t >> 1, d = t & 1;
                 int st = 0;
                 Seg<R> side = robot_side(A, r, sd);
+                const Seg<R> di = pick_dia<R>(dia, d);
                 R md, cd;
-                slope_yint<R>(dia[d].a, dia[d].b, md, cd, st);
-                V2<R> I = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, md, cd, dia[d].a.x); // cached side slope
-                hit = within<R>(I, side, (R)0) & within<R>(I, dia[d], buf);
+                slope_yint<R>(di.a, di.b, md, cd, st);
+                V2<R> I = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, md, cd, di.a.x); // cached side slope
+                hit = within<R>(I, side, (R)0) & within<R>(I, di, buf);
             }
             RR_VOTE(m, l, hit);
         }
         hits |= (uint32_t)(m << base);
     }
-    if (!hits) return -1;
-    int k = 0;
-    while (!((hits >> k) & 1u)) k++;
-    return k;
+    return hits ? low_bit(hits) : -1;
 }
 // same idea for the corner-contact search: first corner (TL,TR,BL,BR) closer to the ball centre than `rad`
 template <class C>
@@ -757,10 +824,7 @@ RR_HD int first_corner_hit(Arena<C> &A, int r, V2<typename C::Real> bc, typename
         }
         hits |= (uint32_t)(m << base);
     }
-    if (!hits) return -1;
-    int k = 0;
-    while (!((hits >> k) & 1u)) k++;
-    return k;
+    return hits ? low_bit(hits) : -1;
 }
 // apply_force_to_ball (RR_TrashyPhysics.py:88-152)
 template <class C> RR_HDN void apply_force_to_ball(Arena<C> &A, const SimParams<typename C::Real> &sp, int r, int b, uint32_t bots_moved, int &st) {
@@ -776,11 +840,12 @@ template <class C> RR_HDN void apply_force_to_ball(Arena<C> &A, const SimParams<
         const int sd = k >> 1, d = k & 1;
         RR_TRACE("E force surface s=%d d=%d b=%d r=%d\n", sd, d, b, r);
         Seg<R> side = robot_side(A, r, sd);
+        const Seg<R> di = pick_dia<R>(dia, d);
         R md, cd;
-        slope_yint<R>(dia[d].a, dia[d].b, md, cd, st);
-        V2<R> I = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, md, cd, dia[d].a.x);
-        R da = dist<R>(dia[d].a, rc), db = dist<R>(dia[d].b, rc);
-        V2<R> cp = (da < db) ? dia[d].a : dia[d].b, opp = (da >= db) ? dia[d].a : dia[d].b;
+        slope_yint<R>(di.a, di.b, md, cd, st);
+        V2<R> I = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, md, cd, di.a.x);
+        R da = dist<R>(di.a, rc), db = dist<R>(di.b, rc);
+        V2<R> cp = (da < db) ? di.a : di.b, opp = (da >= db) ? di.a : di.b;
         fx += (I.x - cp.x) + (opp.x - cp.x) * cbuf / (R)14;
         fy += (I.y - cp.y) + (opp.y - cp.y) * cbuf / (R)14;
         done = true;
@@ -788,11 +853,10 @@ template <class C> RR_HDN void apply_force_to_ball(Arena<C> &A, const SimParams<
         const int c = first_corner_hit(A, r, bc, (R)7 + cbuf);
         if (c >= 0) {
             RR_TRACE("E force corner c=%d b=%d r=%d\n", c, b, r);
-            R px, py, prel[8];
-            robot_prev_frame(A, sp, r, bots_moved, px, py, prel);
+            const PrevPose<R> pv = robot_prev_frame(A, sp, r, bots_moved);
             V2<R> bcn = robot_corner(A, r, c);
             R dc = dist<R>(bcn, bc);
-            V2<R> pc = { px + prel[2 * c], py + prel[2 * c + 1] };
+            V2<R> pc = prev_corner<R>(pv, c);
             V2<R> con = { bc.x - (bcn.x * (R)3 + pc.x) / (R)4, bc.y - (bcn.y * (R)3 + pc.y) / (R)4 };
             R cd = m_sqrt(con.x * con.x + con.y * con.y);
             R ex = ((R)7 - dc) * (R)1.2;
@@ -828,22 +892,22 @@ template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, const SimParams<
     const int k = first_surface_hit(A, r, dia, (R)0);
     const int c = (k >= 0) ? -1 : first_corner_hit(A, r, bc, (R)7);
     if (k >= 0 || c >= 0) {
-        R px, py, prel[8];
-        robot_prev_frame(A, sp, r, bots_moved, px, py, prel);
+        const PrevPose<R> pv = robot_prev_frame(A, sp, r, bots_moved);
         if (k >= 0) {
             const int sd = k >> 1, d = k & 1;
             RR_TRACE("E bounce surface s=%d d=%d b=%d r=%d v=(%.17g,%.17g)\n", sd, d, b, r, (double)vx, (double)vy);
             Seg<R> side = robot_side(A, r, sd);
             const int ca = side_a(sd), cb = side_b(sd);
-            Seg<R> sprev = { { px + prel[2 * ca], py + prel[2 * ca + 1] }, { px + prel[2 * cb], py + prel[2 * cb + 1] } };
+            Seg<R> sprev = { prev_corner<R>(pv, ca), prev_corner<R>(pv, cb) };
+            const Seg<R> di = pick_dia<R>(dia, d);
             R md, cd, mp, cpv;
-            slope_yint<R>(dia[d].a, dia[d].b, md, cd, st);
+            slope_yint<R>(di.a, di.b, md, cd, st);
             slope_yint<R>(sprev.a, sprev.b, mp, cpv, st);
-            V2<R> I = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, md, cd, dia[d].a.x);
-            V2<R> Ip = intersect_mb<R>(mp, cpv, sprev.a.x, md, cd, dia[d].a.x);
-            R da = dist<R>(dia[d].a, Ip), db = dist<R>(dia[d].b, Ip);
-            RR_TRACE("E   I=(%.17g,%.17g) Ip=(%.17g,%.17g) da=%.17g db=%.17g prev=(%.17g,%.17g)\n", (double)I.x, (double)I.y, (double)Ip.x, (double)Ip.y, (double)da, (double)db, (double)px, (double)py);
-            V2<R> cp = (da < db) ? dia[d].a : dia[d].b, opp = (da >= db) ? dia[d].a : dia[d].b;
+            V2<R> I = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, md, cd, di.a.x);
+            V2<R> Ip = intersect_mb<R>(mp, cpv, sprev.a.x, md, cd, di.a.x);
+            R da = dist<R>(di.a, Ip), db = dist<R>(di.b, Ip);
+            RR_TRACE("E   I=(%.17g,%.17g) Ip=(%.17g,%.17g) da=%.17g db=%.17g prev=(%.17g,%.17g)\n", (double)I.x, (double)I.y, (double)Ip.x, (double)Ip.y, (double)da, (double)db, (double)pv.x, (double)pv.y);
+            V2<R> cp = (da < db) ? di.a : di.b, opp = (da >= db) ? di.a : di.b;
             V2<R> con = { opp.x - cp.x, opp.y - cp.y };
             R d2;
             bounce_reflect<R>(con, vx, vy, d2);
@@ -853,7 +917,7 @@ template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, const SimParams<
         } else {
             RR_TRACE("E bounce corner c=%d b=%d r=%d v=(%.17g,%.17g)\n", c, b, r, (double)vx, (double)vy);
             V2<R> bcn = robot_corner(A, r, c);
-            V2<R> pc = { px + prel[2 * c], py + prel[2 * c + 1] };
+            V2<R> pc = prev_corner<R>(pv, c);
             V2<R> con = { bc.x - (bcn.x * (R)3 + pc.x) / (R)4, bc.y - (bcn.y * (R)3 + pc.y) / (R)4 };
             R d2;
             bounce_reflect<R>(con, vx, vy, d2);
@@ -970,8 +1034,8 @@ template <class C> RR_HDN void resolve_bot_collisions(Arena<C> &A, const SimPara
         work += 4;
         if (attempts > C::NR) { st |= ST_BOT_RESOLVE_FAIL; return; }
 #pragma unroll 1
-        for (int p = 0; p < C::NPR; p++) {
-            if (!(pairs & (1u << p))) continue;
+        for (uint32_t todo = pairs; todo; todo &= todo - 1) {
+            const int p = low_bit(todo);
             int i, j;
             pair_of<C>(p, C::NR, i, j);
             // on_robot_collision -> NaughtyBots (RR_ScoreKeepers.py:123-128)
@@ -998,18 +1062,18 @@ template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimPar
         naughty = false;
         uint64_t bb = detect_ball_pairs(A);
 #pragma unroll 1
-        for (int p = 0; p < C::NPB; p++) {
-            if (!(bb & (1ull << p))) continue;
+        for (uint64_t todo = bb; todo; todo &= todo - 1) {
             int i, j;
-            pair_of<C>(p, C::NB, i, j);
+            pair_of<C>(low_bit(todo), C::NB, i, j);
             RR_TRACE("E pass %d bb %d %d\n", count, i, j);
             naughty = true;
             bounce_balls(A, i, j, st);
         }
-        uint32_t br = detect_ball_robot(A, sp);
+        // caches already built in this sub-step (a hit in the push or in an earlier pass)?  then the cheap variant
+        uint32_t br = A.sides_ok ? detect_ball_robot<C, true>(A, sp) : detect_ball_robot<C, false>(A, sp);
 #pragma unroll 1
-        for (int p = 0; p < C::NB * C::NR; p++) {
-            if (!(br & (1u << p))) continue;
+        for (uint32_t todo = br; todo; todo &= todo - 1) {
+            const int p = low_bit(todo);
             naughty = true;
             bounce_ball_off_bot(A, sp, p % C::NR, p / C::NR, bots_moved, st);
         }
@@ -1039,16 +1103,15 @@ RR_HDN void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real>
         uint32_t nbots = 0, nballs = 0;
         uint64_t bb = detect_ball_pairs(A);
 #pragma unroll 1
-        for (int p = 0; p < C::NPB; p++) {
-            if (!(bb & (1ull << p))) continue;
+        for (uint64_t todo = bb; todo; todo &= todo - 1) {
             int i, j;
-            pair_of<C>(p, C::NB, i, j);
+            pair_of<C>(low_bit(todo), C::NB, i, j);
             nballs |= (1u << i) | (1u << j);
         }
-        uint32_t br = detect_ball_robot(A, sp);
+        uint32_t br = A.sides_ok ? detect_ball_robot<C, true>(A, sp) : detect_ball_robot<C, false>(A, sp);
 #pragma unroll 1
-        for (int p = 0; p < C::NB * C::NR; p++) {
-            if (!(br & (1u << p))) continue;
+        for (uint32_t todo = br; todo; todo &= todo - 1) {
+            const int p = low_bit(todo);
             nballs |= 1u << (p / C::NR);
             nbots |= 1u << (p % C::NR);
         }
@@ -1123,11 +1186,11 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     }
     RR_STAMP(2);
     if (m_br) { // _push_balls (RR_EnvBase.py:335-339): frozen hit list, ball-major order
-        uint32_t br = detect_ball_robot(A, sp);
+        uint32_t br = detect_ball_robot<C, false>(A, sp);
         RR_TRACE("E push mask %08x\n", br);
 #pragma unroll 1
-        for (int p = 0; p < C::NB * C::NR; p++) {
-            if (!(br & (1u << p))) continue;
+        for (uint32_t todo = br; todo; todo &= todo - 1) {
+            const int p = low_bit(todo);
             apply_force_to_ball(A, sp, p % C::NR, p / C::NR, bots_moved, st);
             bounce_ball_off_bot(A, sp, p % C::NR, p / C::NR, bots_moved, st);
         }
