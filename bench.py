@@ -139,7 +139,7 @@ def main():
     for i in range(K):
         ev[i][0].record()
         if args.policy == "random":
-            env.step(acts[W + i], out=out)  # exactly one kernel launch between the two events
+            env.step(acts[W + i], out=out)  # k_step (+ the few-microsecond k_order that sorts the next dispatch) between the two events
         else:
             one_step(W + i)
         ev[i][1].record()

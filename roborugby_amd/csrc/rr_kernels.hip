@@ -67,10 +67,14 @@ template <class C, typename O>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void k_step(SimParams<typename C::Real> sp, typename C::Real *recs,
                                                               int32_t *irecs, int n, const int32_t *actions,
                                                               const float *thrust, int na, O *obs, O *reward,
-                                                              uint8_t *done, O *obs_g, O *reward_g, int32_t *status) {
+                                                              uint8_t *done, O *obs_g, O *reward_g, int32_t *status,
+                                                              const uint32_t *order, uint32_t *cost) {
     __shared__ Arena<C> lds[arenas_per_block<C>()];
     const int wave = threadIdx.x / C::VW; // virtual wave = arena slot in this workgroup
-    const int arena = blockIdx.x * arenas_per_block<C>() + wave;
+    // slowest-first dispatch: workgroup b steps the group of arenas that was the b-th slowest in the previous step
+    const unsigned long long t_begin = cost ? __builtin_amdgcn_s_memtime() : 0ull;
+    const int group = order ? (int)order[blockIdx.x] : (int)blockIdx.x;
+    const int arena = group * arenas_per_block<C>() + wave;
     if (arena >= n) return; // uniform per virtual wave; no workgroup barrier is ever used
     Arena<C> &A = lds[wave];
     typename C::Real *rec = recs + (size_t)arena * Arena<C>::P_STRIDE;
@@ -90,12 +94,56 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
     RR_TR();
     store_record(A, rec, irec);
     RR_STAMP(13);
+    if (cost && threadIdx.x == 0) { // what this group cost, in shader clocks / 256 (saturating): next step's dispatch key
+        const unsigned long long dt = (__builtin_amdgcn_s_memtime() - t_begin) >> 8;
+        cost[group] = dt > 0xFFFFull ? 0xFFFFu : (uint32_t)dt;
+    }
 #if defined(RR_PROFILE_PHASES)
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 65536) {
         g_rr_wave_t[2 * blockIdx.x] = rr_wave_t0_;
         g_rr_wave_t[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
+}
+
+// Slowest-first order for the next launch (longest-processing-time-first list scheduling).  A launch ends when its
+// slowest wavefront does and wavefronts differ 3x and more in duration (contact-rich arenas); dispatched in index order a
+// slow one may start in the last round and the chip idles behind it -- measured: 345 us of work per launch stretched
+// to ~500 us.  Contact situations persist over steps, so last step's duration is a good key.  One workgroup, counting
+// sort of the per-group costs into descending order (ties in arbitrary order: results never depend on the order).
+constexpr int ORDER_BINS = 1024, ORDER_THREADS = 1024;
+__global__ __launch_bounds__(ORDER_THREADS) void k_order(const uint32_t *cost, uint32_t *order, int ngroups) {
+    __shared__ uint32_t hist[ORDER_BINS];
+    for (int i = threadIdx.x; i < ORDER_BINS; i += ORDER_THREADS) hist[i] = 0;
+    __syncthreads();
+    for (int g = threadIdx.x; g < ngroups; g += ORDER_THREADS) {
+        uint32_t c = cost[g] >> 2; // 1,024 clocks per bin: 0 .. ~1M clocks (0.4 ms) resolved, slower groups share the first bin
+        c = c > ORDER_BINS - 1 ? ORDER_BINS - 1 : c;
+        atomicAdd(&hist[ORDER_BINS - 1 - c], 1u);
+    }
+    __syncthreads();
+    // exclusive prefix sum over the bins (one thread per bin, Hillis-Steele in LDS)
+    __shared__ uint32_t scan[ORDER_BINS];
+    uint32_t v = hist[threadIdx.x];
+    scan[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < ORDER_BINS; off <<= 1) {
+        uint32_t add = threadIdx.x >= (unsigned)off ? scan[threadIdx.x - off] : 0u;
+        __syncthreads();
+        scan[threadIdx.x] += add;
+        __syncthreads();
+    }
+    hist[threadIdx.x] = scan[threadIdx.x] - v; // start offset of the bin
+    __syncthreads();
+    for (int g = threadIdx.x; g < ngroups; g += ORDER_THREADS) {
+        uint32_t c = cost[g] >> 2;
+        c = c > ORDER_BINS - 1 ? ORDER_BINS - 1 : c;
+        order[atomicAdd(&hist[ORDER_BINS - 1 - c], 1u)] = (uint32_t)g;
+    }
+}
+__global__ void k_iota(uint32_t *order, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) order[i] = (uint32_t)i;
 }
 
 // env.reset() for masked arenas; also used (init = 1) to build the constructor's state
@@ -284,6 +332,9 @@ struct rr_env {
     bool custom_prog;    // != SimpleDuel3's {Naughty, Chase, PushPos}
     void *xs;            // on_step_begin snapshot for the side kernels (lazy)
     int32_t *status_buf; // internal status when the caller passes none but the side kernels need it (lazy)
+    uint32_t *order;     // slowest-first dispatch order of the arena groups (null: index order)
+    uint32_t *cost;      // last step's duration per group
+    int ngroups;
 };
 
 static thread_local std::string g_err;
@@ -381,8 +432,27 @@ int rr_create(const rr_config *cfg, rr_env **out) {
         delete e;
         return fail(-3, std::string("rr_create: hipMalloc: ") + hipGetErrorString(he));
     }
-    // constructor placement (RR_EnvBase.py:111-116): episode 0 of the counter RNG
     const int n = cfg->num_envs;
+    // slowest-first dispatch pays once the groups outnumber the wavefronts resident at a time (a few thousand); one
+    // workgroup sorts up to 65,536 keys in a few microseconds.  RR_NO_ORDER=1 switches it off (A/B runs).
+    e->order = nullptr; e->cost = nullptr; e->ngroups = 0;
+    {
+        int apb = 1;
+        dispatch(e, [&](auto c) { using CC = decltype(c); apb = arenas_per_block<CC>(); return 0; });
+        const int ng = (n + apb - 1) / apb;
+        const char *no = getenv("RR_NO_ORDER");
+        if (ng > 2048 && ng <= 65536 && !(no && atoi(no))) {
+            if (hipMalloc((void **)&e->order, sizeof(uint32_t) * ng) == hipSuccess && hipMalloc((void **)&e->cost, sizeof(uint32_t) * ng) == hipSuccess) {
+                e->ngroups = ng;
+                hipLaunchKernelGGL(k_iota, dim3((ng + 255) / 256), dim3(256), 0, 0, e->order, ng);
+                (void)hipMemset(e->cost, 0, sizeof(uint32_t) * ng);
+            } else {
+                if (e->order) (void)hipFree(e->order);
+                e->order = nullptr; e->cost = nullptr;
+            }
+        }
+    }
+    // constructor placement (RR_EnvBase.py:111-116): episode 0 of the counter RNG
     dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
         hipLaunchKernelGGL((k_reset<CC, float>), arena_grid<CC>(n), wave_block(), 0, 0, params_of<RR>(e), (RR *)e->recs,
@@ -393,6 +463,8 @@ int rr_create(const rr_config *cfg, rr_env **out) {
     if (he == hipSuccess) he = hipDeviceSynchronize();
     if (he != hipSuccess) {
         (void)hipFree(e->recs); (void)hipFree(e->irecs);
+        if (e->order) (void)hipFree(e->order);
+        if (e->cost) (void)hipFree(e->cost);
         delete e;
         return fail(-2, std::string("rr_create: init kernel: ") + hipGetErrorString(he));
     }
@@ -407,6 +479,8 @@ int rr_destroy(rr_env *e) {
     (void)hipFree(e->irecs);
     if (e->xs) (void)hipFree(e->xs);
     if (e->status_buf) (void)hipFree(e->status_buf);
+    if (e->order) (void)hipFree(e->order);
+    if (e->cost) (void)hipFree(e->cost);
     delete e;
     return 0;
 }
@@ -452,7 +526,8 @@ static int step_impl(rr_env *e, const int32_t *actions, const float *thrust, int
             if (e->custom_prog)
                 hipLaunchKernelGGL((k_extras_begin<CC>), dim3((n + 127) / 128), dim3(128), 0, s, (const RR *)e->recs, n, (RR *)e->xs);
             hipLaunchKernelGGL((k_step<CC, O>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (RR *)e->recs, e->irecs, n,
-                               actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status);
+                               actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status, (const uint32_t *)e->order, e->cost);
+            if (e->order) hipLaunchKernelGGL(k_order, dim3(1), dim3(ORDER_THREADS), 0, s, (const uint32_t *)e->cost, e->order, e->ngroups);
             if (e->custom_prog)
                 hipLaunchKernelGGL((k_extras_end<CC, O>), dim3((n + 127) / 128), dim3(128), 0, s, params_of<RR>(e),
                                    (const RR *)e->recs, n, (const RR *)e->xs, e->prog, reward, reward_g, status);

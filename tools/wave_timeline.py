@@ -47,7 +47,7 @@ for rep in range(warm + 3):
                 rb = before['robots'][a_]; bl = before['balls'][a_]
                 dmin = min(float(np.hypot(bl[b, 0] - rb[r, 0], bl[b, 1] - rb[r, 1])) for b in range(bl.shape[0]) for r in range(rb.shape[0]))
                 wall = float(min(bl[:, 0].min(), bl[:, 1].min(), (env.preset.arena_w - bl[:, 0]).min(), (env.preset.arena_h - bl[:, 1]).min()))
-                rr_ = min(float(np.hypot(rb[i, 0] - rb[j, 0], rb[i, 1] - rb[j, 1])) for i in range(rb.shape[0]) for j in range(i))
-                bb_ = min(float(np.hypot(bl[i, 0] - bl[j, 0], bl[i, 1] - bl[j, 1])) for i in range(bl.shape[0]) for j in range(i))
+                rr_ = min([float(np.hypot(rb[i, 0] - rb[j, 0], rb[i, 1] - rb[j, 1])) for i in range(rb.shape[0]) for j in range(i)] or [float('inf')])
+                bb_ = min([float(np.hypot(bl[i, 0] - bl[j, 0], bl[i, 1] - bl[j, 1])) for i in range(bl.shape[0]) for j in range(i)] or [float('inf')])
                 rw_ = float(min(rb[:, 2].min(), rb[:, 4].min(), (env.preset.arena_w - rb[:, 3]).min(), (env.preset.arena_h - rb[:, 5]).min()))
                 print(f"    arena {a_}: min ball-robot {dmin:.1f} robot-robot {rr_:.1f} ball-ball {bb_:.1f} ball-wall {wall:.1f} robot-edge-wall {rw_:.2f} |v|max {np.abs(bl[:, 6:8]).max():.3f} actions {a[a_].tolist()}")
