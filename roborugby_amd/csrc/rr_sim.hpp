@@ -61,11 +61,16 @@
     } while (0)
 // ballot restricted to this lane's virtual wave (inactive / diverged lanes contribute 0)
 #define RR_VOTE(mask, l, pred) (mask) = rr::vballot<C::VW>(pred)
+// a per-lane value that lives across two lane-parallel phases: a plain register here, an array in the host emulation
+#define RR_LANE_VAR(type, name) type name
+#define RR_LV(name, l) name
 #else
 #define RR_FOR_LANES(l) for (int l = 0; l < C::VW; ++l)
 #define RR_IS_LANE0 true
 #define RR_SYNC() do { } while (0)
 #define RR_VOTE(mask, l, pred) (mask) |= ((uint64_t)((pred) ? 1 : 0)) << (l)
+#define RR_LANE_VAR(type, name) type name[C::VW]
+#define RR_LV(name, l) name[l]
 #endif
 
 // Diagnostic build only (-DRR_PROFILE_PHASES): per-phase cycle totals of the leader lane of every 64th wavefront,
@@ -315,6 +320,7 @@ template <class C> struct ArenaBody {
     R bfx[NB], bfy[NB], pfx[NB], pfy[NB];
     int32_t bmass[NB];
     int32_t bbm[NB], brc[NB]; // per-ball hit / close bit masks of the contact sweeps (one lane per ball writes its own)
+    R exc[NB];                // how far (L1) the contact responses of this sub-step have carried the ball from its frame-begin centre
     int32_t sides_ok; // sm/sc match the current robot poses (rebuilt lazily by the first phase that needs them)
     union { // the lidar candidates are only alive inside observe(), the inner-square offsets only inside a sub-step
         R irel[NR][8];                    // corner offsets of the ball's inner square at rot+45 (diameter end points)
@@ -485,7 +491,21 @@ template <class C> RR_HD void robot_move_lane(Arena<C> &A, const SimParams<typen
         }
         if (rob_hit_wall<R>(f, sp)) {
             fr_set_cx<R>(f, px); fr_set_cy<R>(f, py);
-            fr_set_rot<R>(f, rot_prior, sp.rob_cdist);
+            // `self.rectDbl.rotation = dblPriorRot` (RR_Robot.py:226): the setter on (rot_prior + 720) % 360.  With 32 robots
+            // per wavefront some robot is blocked by a wall while turning in most sub-steps, so this path is hot.  The
+            // normalised value is almost always rot_prior itself (it came out of this very normalisation one move ago),
+            // and then the corners the setter would rebuild are the ones still sitting in LDS: A.rel is always
+            // corners_for(rrot) and store_robot has not run yet.  Only a value the +720 really perturbs pays the trig.
+            const R nr = py_mod<R>(rot_prior + (R)720, (R)360);
+            if (nr != f.rot) {
+                f.rot = nr;
+                if (nr == rot_prior) {
+                    for (int k = 0; k < 8; k++) f.rel[k] = A.rel[r][k];
+                } else {
+                    corners_for<R>(nr, (R)10, (R)20, sp.rob_cdist, f.rel);
+                }
+                fr_edges_from_rel<R>(f);
+            }
         }
     }
     rob_clamp<R>(f, sp);
@@ -736,6 +756,15 @@ template <class C> RR_HD uint32_t detect_ball_wall(const Arena<C> &A, const SimP
     return (uint32_t)m;
 }
 
+// excursion bookkeeping for the island freeze (see substep): called after every position write of the contact paths
+template <class C> RR_HD void ball_exc_update(Arena<C> &A, int b) {
+    using R = typename C::Real;
+    if (C::NR < 2) return; // no islands in a one-robot arena
+    const R e = m_abs(A.p.bcx[b] - A.pfx[b]) + m_abs(A.p.bcy[b] - A.pfy[b]);
+    if (e > A.exc[b]) A.exc[b] = e;
+}
+struct Hit { uint32_t r, b; }; // robots / balls that took part in a hit (response, undo) during the sub-step
+
 // ------------------------------------------------------------------------------------------------ contact responses (wave-uniform, list order)
 // rectDblPriorFrame (RR_Robot.py:43-58): pose at the start of the robot's last move that was not undone.  Only the
 // (rare) contact responses need its corners, so they are rebuilt here on demand exactly like the reference does
@@ -934,6 +963,7 @@ template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, const SimParams<
         ball_shift(A, b, nx - bc.x, (R)0);
         R ny = bc.y + mvy;
         ball_shift(A, b, (R)0, ny - bc.y);
+        ball_exc_update(A, b);
     }
     RR_SYNC();
 }
@@ -984,6 +1014,7 @@ template <class C> RR_HDN void bounce_balls(Arena<C> &A, int i, int j, int &st) 
         ball_shift(A, j, (R)0, n2y - y2);
         A.bmass[i] = m1; A.bmass[j] = m2;
         A.p.bvx[i] = v1x; A.p.bvy[i] = v1y; A.p.bvx[j] = v2x; A.p.bvy[j] = v2y;
+        ball_exc_update(A, i); ball_exc_update(A, j);
     }
     RR_SYNC();
 }
@@ -994,6 +1025,7 @@ template <class C> RR_HD void bounce_ball_off_wall_lane(Arena<C> &A, const SimPa
     if (A.p.brt[b] > sp.W) { R v = sp.W - (A.p.brt[b] - sp.W) * (R)1.1; ball_shift(A, b, v - A.p.brt[b], (R)0); A.p.bvx[b] *= (R)-1 * (R).8; A.bmass[b] = 3; }
     if (A.p.bt[b] <= (R)0) { R v = A.p.bt[b] * (R)-1.1; ball_shift(A, b, (R)0, v - A.p.bt[b]); A.p.bvy[b] *= (R)-1 * (R).8; A.bmass[b] = 3; }
     if (A.p.bb[b] >= sp.H) { R v = sp.H - (A.p.bb[b] - sp.W) * (R)1.1; ball_shift(A, b, (R)0, v - A.p.bb[b]); A.p.bvy[b] *= (R)-1 * (R).8; A.bmass[b] = 3; }
+    ball_exc_update(A, b);
 }
 // Ball.move (RR_Ball.py:78-105)
 template <class C> RR_HD void ball_move_lane(Arena<C> &A, int b) {
@@ -1025,7 +1057,7 @@ template <class C> RR_HD void ball_undo_lane(Arena<C> &A, int b) {
 }
 
 // ------------------------------------------------------------------------------------------------ sub-step pieces (RR_EnvBase.py:303-454)
-template <class C> RR_HDN void resolve_bot_collisions(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &bots_moved, uint32_t &naughty, int &st, int &work) {
+template <class C> RR_HDN void resolve_bot_collisions(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &bots_moved, uint32_t &naughty, int &st, int &work, Hit &hit) {
     if (C::NPR == 0) return;
     uint32_t pairs = detect_robot_pairs(A);
     int attempts = 0;
@@ -1038,6 +1070,7 @@ template <class C> RR_HDN void resolve_bot_collisions(Arena<C> &A, const SimPara
             const int p = low_bit(todo);
             int i, j;
             pair_of<C>(p, C::NR, i, j);
+            hit.r |= (1u << i) | (1u << j);
             // on_robot_collision -> NaughtyBots (RR_ScoreKeepers.py:123-128)
             if (A.i.thl[i] != 0 || A.i.thr[i] != 0) naughty |= 1u << i;
             if (A.i.thl[j] != 0 || A.i.thr[j] != 0) naughty |= 1u << j;
@@ -1052,9 +1085,10 @@ template <class C> RR_HDN void resolve_bot_collisions(Arena<C> &A, const SimPara
         pairs = detect_robot_pairs(A);
     }
 }
-template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t bots_moved, int &st, int &work) {
+template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t bots_moved, int &st, int &work, Hit &hit) {
     bool naughty = true;
     int count = 0;
+    RR_FOR_LANES(l) { if (l < C::NB) ball_exc_update(A, l); } // where the push and the roll have left each ball
     while (naughty) {
         count++;
         work++;
@@ -1066,6 +1100,7 @@ template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimPar
             int i, j;
             pair_of<C>(low_bit(todo), C::NB, i, j);
             RR_TRACE("E pass %d bb %d %d\n", count, i, j);
+            hit.b |= (1u << i) | (1u << j);
             naughty = true;
             bounce_balls(A, i, j, st);
         }
@@ -1075,11 +1110,13 @@ template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimPar
         for (uint32_t todo = br; todo; todo &= todo - 1) {
             const int p = low_bit(todo);
             naughty = true;
+            hit.b |= 1u << (p / C::NR); hit.r |= 1u << (p % C::NR);
             bounce_ball_off_bot(A, sp, p % C::NR, p / C::NR, bots_moved, st);
         }
         uint32_t bw = detect_ball_wall(A, sp);
         if (bw) {
             naughty = true;
+            hit.b |= bw;
             RR_FOR_LANES(l) {
                 if (l < C::NB && (bw & (1u << l))) bounce_ball_off_wall_lane(A, sp, l);
             }
@@ -1090,7 +1127,7 @@ template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimPar
 }
 template <class C>
 RR_HDN void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &balls_moved,
-                                 uint32_t &bots_moved, int &st) {
+                                 uint32_t &bots_moved, int &st, Hit &hit) {
     bool naughty = true;
     int count = 0;
     const int limit = C::NB + C::NR;
@@ -1117,6 +1154,7 @@ RR_HDN void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real>
         }
         nballs |= detect_ball_wall(A, sp);
         naughty = (nbots | nballs) != 0;
+        hit.r |= nbots; hit.b |= nballs;
         uint32_t ubots = bots_moved & nbots, uballs = balls_moved & nballs;
         bots_moved &= ~ubots;
         balls_moved &= ~uballs;
@@ -1137,17 +1175,61 @@ RR_HDN void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real>
     }
 }
 
+// _push_balls over a frozen hit list (RR_EnvBase.py:335-339), ball-major order
+template <class C>
+RR_HD void push_balls(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t br, uint32_t bots_moved, int &st, Hit &hit) {
+#pragma unroll 1
+    for (uint32_t todo = br; todo; todo &= todo - 1) {
+        const int p = low_bit(todo);
+        hit.b |= 1u << (p / C::NR); hit.r |= 1u << (p % C::NR);
+        apply_force_to_ball(A, sp, p % C::NR, p / C::NR, bots_moved, st);
+        bounce_ball_off_bot(A, sp, p % C::NR, p / C::NR, bots_moved, st);
+    }
+}
+// the frozen island catches up with phase 1: frame hooks of its robots and balls, and the robots' moves
+template <class C> RR_HD void thaw_island(Arena<C> &A, const SimParams<typename C::Real> &sp, Hit &fz, uint32_t &bots_moved) {
+    using R = typename C::Real;
+    RR_FOR_LANES(l) {
+        if (l < C::NR && ((fz.r >> l) & 1u)) { // (no ring update: a frozen robot's previous move was undone)
+            A.ax[l] = A.p.rcx[l]; A.ay[l] = A.p.rcy[l]; A.arot[l] = A.p.rrot[l];
+            robot_move_lane(A, sp, l);
+        }
+        if (l < C::NB && ((fz.b >> l) & 1u)) {
+            A.bmass[l] = 1; A.bfx[l] = (R)0; A.bfy[l] = (R)0; A.exc[l] = (R)0;
+            A.pfx[l] = ball_copy_c<R>(A.p.bcx[l]); A.pfy[l] = ball_copy_c<R>(A.p.bcy[l]);
+        }
+    }
+    RR_SYNC();
+    bots_moved |= fz.r;
+    fz.r = 0; fz.b = 0;
+}
+
 // one of the 12 physics sub-steps ("frame", RR_EnvBase.py:275-287).
 // Wall time per sub-step is set by the number of dependent phases (LDS round trip + ballot each), not by their
-// arithmetic, so the common no-contact path is folded into four phases: [frame hooks + robot moves],
-// [robot-robot + ball-robot broad phase], [roll], [ball-ball + ball-robot broad phase + wall test].  Only when a
-// ballot reports something close do the reference-shaped loops below (unchanged, exact) run.
+// arithmetic, so the common no-contact path is folded into two phases: [frame hooks + robot moves + robot-robot and
+// ball-robot broad phase] and [roll + ball-ball / ball-robot broad phase + wall test], with motion-aware bounds.  Only
+// when a ballot reports something close do the reference-shaped loops below (unchanged, exact) run.
 // `prev_moved`: robots whose move of the previous sub-step survived (their ring entry moveCount-1 is that frame's).
-// `work`: += the contact-resolution passes this sub-step ran (0 on the common path); feeds the fixed-point check below.
+// `work`: += the contact-resolution passes this sub-step ran (0 on the common path); `hit`: who took part in them.
+//
+// Island freeze (`fz`).  A stuck island -- a ball squeezed between two robots, robots locked against each other --
+// costs ~150 quiet sub-steps per sub-step (push, ten resolve passes, undo loop) and ends every sub-step exactly where
+// it began, while the rest of the arena moves on; one such arena used to set the duration of a 65,536-arena launch.
+// The sub-step is deterministic, and entities only influence each other through pair tests that HIT.  So once the
+// entities that took part in the hits of a sub-step (the island K = fz.r | fz.b) are found bit-identical to what
+// they were a sub-step earlier (step_arena checks that), the next sub-step maps K onto itself again PROVIDED nothing
+// outside K hits K -- and then K need not be recomputed at all.  A frozen sub-step therefore runs the two fast phases
+// for everything outside K and keeps K as an obstacle: its robots with the usual motion slack, its balls with the
+// excursion `exc` their responses reached while the island was last computed.  If every broad test involving an
+// entity outside K stays negative, nothing outside K touched anything (K included) and the sub-step is complete: exact.
+// If any fires, the island is thawed on the spot: its robots make the move they skipped (moves are independent per
+// robot), its balls run their frame hooks (and, if the thaw comes after the roll phase, the push restricted to K and
+// their roll), and the reference-shaped path runs for the whole arena as if it had never been frozen.
 template <class C>
-RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &naughty, int &st, uint32_t &prev_moved, int &work) {
+RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &naughty, int &st, uint32_t &prev_moved,
+                   int &work, Hit &fz, Hit &hit) {
     using R = typename C::Real;
-    uint32_t bots_moved = (1u << C::NR) - 1, balls_moved = (1u << C::NB) - 1;
+    uint32_t bots_moved = ((1u << C::NR) - 1) & ~fz.r, balls_moved = (1u << C::NB) - 1;
     RR_TRACE("E substep\n");
     RR_T0();
     // phase 1: frame hooks, robot moves AND the exact broad phase.  The broad phase runs in the same phase as the moves:
@@ -1156,23 +1238,32 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     uint64_t m_rr = 0, m_br = 0;
     RR_FOR_LANES(l) {
         bool c_rr = false, c_br = false;
-        if (l < C::NR) {
+        if (l < C::NR && !((fz.r >> l) & 1u)) {
             if (prev_moved & (1u << l)) { A.p.px[l] = A.ax[l]; A.p.py[l] = A.ay[l]; A.p.prot[l] = A.arot[l]; }
             // on_frame_begin (RR_Robot.py:119-120): the ring entry written this frame
             const R ox = A.p.rcx[l], oy = A.p.rcy[l];
             A.ax[l] = ox; A.ay[l] = oy; A.arot[l] = A.p.rrot[l];
             for (int j = 0; j < C::NR; j++) { // robot-robot: needs centres within 2 x 22.36 (+ 2 x 3 px of motion)
                 R dx = A.p.rcx[j] - ox, dy = A.p.rcy[j] - oy;
-                c_rr = c_rr | ((j > l) & (dx * dx + dy * dy <= (R)(51.5 * 51.5)));
+                // each pair once (j > l); a frozen j has no lane of its own in this phase, so its partner tests the pair
+                c_rr = c_rr | (((j > l) | (((fz.r >> j) & 1u) != 0)) & (j != l) & (dx * dx + dy * dy <= (R)(51.5 * 51.5)));
             }
             robot_move_lane(A, sp, l); // _move_bots
         }
-        if (l < C::NB) { // on_frame_begin (RR_Ball.py:63-68)
-            A.bmass[l] = 1; A.bfx[l] = (R)0; A.bfy[l] = (R)0;
-            A.pfx[l] = ball_copy_c<R>(A.p.bcx[l]); A.pfy[l] = ball_copy_c<R>(A.p.bcy[l]);
-            for (int r = 0; r < C::NR; r++) { // ball-robot: 22.36 + 9.9 (+ 3 px of robot motion)
-                R dx = A.p.bcx[l] - A.p.rcx[r], dy = A.p.bcy[l] - A.p.rcy[r];
-                c_br = c_br | (dx * dx + dy * dy <= (R)(36.0 * 36.0));
+        if (l < C::NB) {
+            if (!((fz.b >> l) & 1u)) { // on_frame_begin (RR_Ball.py:63-68)
+                A.bmass[l] = 1; A.bfx[l] = (R)0; A.bfy[l] = (R)0; A.exc[l] = (R)0;
+                A.pfx[l] = ball_copy_c<R>(A.p.bcx[l]); A.pfy[l] = ball_copy_c<R>(A.p.bcy[l]);
+                for (int r = 0; r < C::NR; r++) { // ball-robot: 22.36 + 9.9 (+ 3 px of robot motion)
+                    R dx = A.p.bcx[l] - A.p.rcx[r], dy = A.p.bcy[l] - A.p.rcy[r];
+                    c_br = c_br | (dx * dx + dy * dy <= (R)(36.0 * 36.0));
+                }
+            } else { // frozen ball: anywhere within its recorded excursion, against the robots outside the island
+                const R reach = (R)36.05 + A.exc[l];
+                for (int r = 0; r < C::NR; r++) {
+                    R dx = A.p.bcx[l] - A.p.rcx[r], dy = A.p.bcy[l] - A.p.rcy[r];
+                    c_br = c_br | ((((fz.r >> r) & 1u) == 0) & (dx * dx + dy * dy <= reach * reach));
+                }
             }
         }
         RR_VOTE(m_rr, l, c_rr);
@@ -1180,20 +1271,20 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     }
     RR_SYNC();
     RR_STAMP(1);
+    if ((fz.r | fz.b) && (m_rr | m_br)) { // thaw before anything depended on the island
+        RR_TRACE("E thaw in phase 1\n");
+        thaw_island(A, sp, fz, bots_moved);
+        m_rr = 1; m_br = 1;
+    }
     if (m_rr) {
-        resolve_bot_collisions(A, sp, bots_moved, naughty, st, work);
+        resolve_bot_collisions(A, sp, bots_moved, naughty, st, work, hit);
         m_br = 1; // an undone robot changes the ball-robot picture: let the full detection decide
     }
     RR_STAMP(2);
     if (m_br) { // _push_balls (RR_EnvBase.py:335-339): frozen hit list, ball-major order
         uint32_t br = detect_ball_robot<C, false>(A, sp);
         RR_TRACE("E push mask %08x\n", br);
-#pragma unroll 1
-        for (uint32_t todo = br; todo; todo &= todo - 1) {
-            const int p = low_bit(todo);
-            apply_force_to_ball(A, sp, p % C::NR, p / C::NR, bots_moved, st);
-            bounce_ball_off_bot(A, sp, p % C::NR, p / C::NR, bots_moved, st);
-        }
+        push_balls(A, sp, br, bots_moved, st, hit);
     }
     RR_STAMP(3);
     // phase 2: _roll_balls AND the fused first pass of _resolve_ball_collisions: anything possibly touching?  Ball-ball
@@ -1203,28 +1294,59 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     uint64_t m_any = 0;
     RR_FOR_LANES(l) {
         bool c = false;
-        if (l < C::NB) {
+        if (l < C::NB && !((fz.b >> l) & 1u)) {
             ball_move_lane(A, l);
             const R mx = A.p.bcx[l], my = A.p.bcy[l];
             for (int j = 0; j < C::NB; j++) {
                 R dx = A.p.bcx[j] - mx, dy = A.p.bcy[j] - my;
                 R tr = (m_abs(A.p.bvx[j]) + m_abs(A.bfx[j]) + m_abs(A.p.bvy[j]) + m_abs(A.bfy[j])) * (R)1.01 + (R)0.02;
+                tr = ((fz.b >> j) & 1u) ? A.exc[j] + (R)0.02 : tr; // a frozen ball: wherever its island carried it
                 R reach = (R)14.04 + tr;
                 c = c | ((j != l) & (dx * dx + dy * dy <= reach * reach));
             }
-            for (int r = 0; r < C::NR; r++) c = c | ball_near_robot(A, l, r);
+            for (int r = 0; r < C::NR; r++) {
+                if ((fz.r >> r) & 1u) { // a frozen robot: its frame-begin or its (undone) moved pose -- the radius bound + 3 px
+                    R dx = mx - A.p.rcx[r], dy = my - A.p.rcy[r];
+                    c = c | (dx * dx + dy * dy <= (R)(36.0 * 36.0));
+                } else {
+                    c = c | ball_near_robot(A, l, r);
+                }
+            }
             c = c | ball_collided_wall(A, sp, l);
         }
         RR_VOTE(m_any, l, c);
     }
     RR_SYNC();
     RR_STAMP(4);
+    if ((fz.r | fz.b) && m_any) { // thaw after the roll phase: the island catches up (move, push, roll), then the full path
+        RR_TRACE("E thaw in phase 2\n");
+        const Hit k = fz;
+        thaw_island(A, sp, fz, bots_moved);
+        resolve_bot_collisions(A, sp, bots_moved, naughty, st, work, hit);
+        // the push saw the other balls before their roll and found none of them near a robot (phase 1): only K's pairs count
+        uint32_t kmask = 0;
+        for (int b = 0; b < C::NB; b++) if ((k.b >> b) & 1u) kmask |= ((1u << C::NR) - 1u) << (b * C::NR);
+        uint32_t br = detect_ball_robot<C, false>(A, sp) & kmask;
+        push_balls(A, sp, br, bots_moved, st, hit);
+        RR_FOR_LANES(l) { if (l < C::NB && ((k.b >> l) & 1u)) ball_move_lane(A, l); }
+        RR_SYNC();
+    }
     if (m_any) { // the reference's loop, from its first pass (nothing has changed since the broad phase above)
-        bool rr_ok_ = resolve_ball_collisions(A, sp, bots_moved, st, work);
+        bool rr_ok_ = resolve_ball_collisions(A, sp, bots_moved, st, work, hit);
         RR_STAMP(5);
-        if (!rr_ok_) { work += 8; undo_naughty_movement(A, sp, balls_moved, bots_moved, st); }
+        if (!rr_ok_) { work += 8; undo_naughty_movement(A, sp, balls_moved, bots_moved, st, hit); }
     }
     RR_STAMP(6);
+    if (fz.r) { // still frozen: the island's robots would have moved and been undone -- replay that arithmetic on their records
+        RR_FOR_LANES(l) {
+            if (l < C::NR && ((fz.r >> l) & 1u)) {
+                A.ax[l] = A.p.rcx[l]; A.ay[l] = A.p.rcy[l]; A.arot[l] = A.p.rrot[l];
+                robot_move_lane(A, sp, l);
+                robot_undo_lane(A, sp, l);
+            }
+        }
+        RR_SYNC();
+    }
     prev_moved = bots_moved;
 }
 // after the last sub-step: the pose-ring bookkeeping the next sub-step would have done
@@ -1479,6 +1601,18 @@ template <typename O> struct StepOut {
 // same bits into `naughty` / `st`): the loop can stop.  Exact, not approximate.
 // The comparison is bitwise (NaN-safe), lane-strided, against a snapshot kept in the arena's own HBM record (dead
 // between load_record and store_record); it is only made after sub-steps that ran the expensive contact paths.
+// the robots in `mask` keep their AABB at least 6 px inside the arena: a move shifts an edge by < 2 px, so the wall test /
+// clamp of their move (RR_Robot.py:188-203) cannot fire and cannot depend on the last bits of the edges
+template <class C> RR_HD bool robots_clear_of_walls(const Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t mask) {
+    using R = typename C::Real;
+    uint64_t near = 0;
+    RR_FOR_LANES(l) {
+        const bool nw = (l < C::NR) && ((mask >> l) & 1u) &&
+                        !(A.p.rl[l] > (R)6 && A.p.rrt[l] < sp.W - (R)6 && A.p.rt[l] > (R)6 && A.p.rb[l] < sp.H - (R)6);
+        RR_VOTE(near, l, nw);
+    }
+    return !near;
+}
 // cheap necessary condition, from LDS only: every robot ends the sub-step on its frame-begin pose (undone, blocked or idle)
 template <class C> RR_HD bool robots_unmoved(const Arena<C> &A) {
     uint64_t any_moved = 0;
@@ -1488,32 +1622,58 @@ template <class C> RR_HD bool robots_unmoved(const Arena<C> &A) {
     }
     return !any_moved;
 }
-template <class C> RR_HD bool snapshot_same_and_update(const Arena<C> &A, uint32_t *snap, int32_t *isnap, bool have) {
+// Compares the arena with the snapshot of one sub-step earlier, word by word, and refreshes the snapshot.  Out: the
+// robots whose pose / pose history / move counter changed (chg_r), the robots whose AABB edges changed (chg_re: the edges
+// are kept incrementally, MyUtils.py:141-148, and a move + undo does not always give them back to the last bit), the balls
+// that changed, and whether any frame-begin pose ax/ay/arot did.  Without a valid snapshot everything counts as changed.
+template <class C>
+RR_HD void snapshot_compare_update(const Arena<C> &A, uint32_t *snap, int32_t *isnap, bool have, uint32_t &chg_r, uint32_t &chg_re,
+                                   uint32_t &chg_b, bool &ax_diff) {
     using R = typename C::Real;
+    constexpr int WR = (int)(sizeof(R) / 4);
     constexpr int NW = (int)(sizeof(typename Arena<C>::P) / 4);   // the persistent reals ...
-    constexpr int NA = (int)(3 * C::NR * sizeof(R) / 4);          // ... + ax, ay, arot: the frame-begin poses the next sub-step's ring update reads
+    constexpr int NA = 3 * C::NR * WR;                            // ... + ax, ay, arot: the frame-begin poses the next sub-step's ring update reads
     static_assert(Arena<C>::P_STRIDE * sizeof(R) / 4 >= (size_t)(NW + NA), "the HBM record holds the snapshot");
     static_assert(offsetof(ArenaBody<C>, ay) == offsetof(ArenaBody<C>, ax) + C::NR * sizeof(R) &&
                   offsetof(ArenaBody<C>, arot) == offsetof(ArenaBody<C>, ax) + 2 * C::NR * sizeof(R), "ax, ay, arot are contiguous");
     const uint32_t *p = reinterpret_cast<const uint32_t *>(&A.p);
     const uint32_t *q = reinterpret_cast<const uint32_t *>(&A.ax[0]);
-    uint64_t any_diff = 0;
+    uint32_t cr = 0, cre = 0, cb = 0;
+    uint64_t any_ax = 0, m = 0;
+    constexpr int NE = 2 * C::NR + C::NB; // bits: robots (core), robots (edges), balls
+    RR_LANE_VAR(uint32_t, mine_of);
+    // each lane collects the entities its words belong to; the masks are then OR-ed over the lanes bit by bit (ballots)
     RR_FOR_LANES(l) {
-        bool diff = false;
+        uint32_t mine = 0; // bits 0..NR-1 robots (core fields), NR..2NR-1 robots (edge fields 2..5), 2NR.. balls
+        bool axd = false;
         for (int k = l; k < NW + NA; k += C::VW) {
             const uint32_t v = k < NW ? p[k] : q[k - NW];
-            if (have) diff = diff | (snap[k] != v);
-            if (have && snap[k] != v) RR_TRACE("E   snapshot word %d differs\n", k);
+            const bool d = !have || snap[k] != v;
             snap[k] = v;
+            if (k < NW) {
+                const int idx = k / WR; // index of the real inside P: 10 robot fields x NR, 8 ball fields x NB, acc[4]
+                if (idx < 10 * C::NR) {
+                    const int fld = idx / C::NR; // rcx rcy | rl rrt rt rb | rrot px py prot
+                    mine |= d ? (1u << (idx % C::NR + ((fld >= 2 && fld <= 5) ? C::NR : 0))) : 0u;
+                } else if (idx < 10 * C::NR + 8 * C::NB) mine |= d ? (1u << (2 * C::NR + (idx - 10 * C::NR) % C::NB)) : 0u;
+            } else {
+                axd = axd | d;
+            }
         }
         for (int k = l; k < C::NR; k += C::VW) {
             const int32_t v = A.i.mc[k];
-            if (have) diff = diff | (isnap[k] != v);
+            mine |= (!have || isnap[k] != v) ? (1u << k) : 0u;
             isnap[k] = v;
         }
-        RR_VOTE(any_diff, l, diff);
+        RR_VOTE(any_ax, l, axd);
+        RR_LV(mine_of, l) = mine;
     }
-    return have && !any_diff;
+    for (int e = 0; e < NE; e++) {
+        m = 0;
+        RR_FOR_LANES(l) { RR_VOTE(m, l, (RR_LV(mine_of, l) >> e) & 1u); }
+        if (m) { if (e < C::NR) cr |= 1u << e; else if (e < 2 * C::NR) cre |= 1u << (e - C::NR); else cb |= 1u << (e - 2 * C::NR); }
+    }
+    chg_r = cr; chg_re = cre; chg_b = cb; ax_diff = any_ax != 0;
 }
 
 // actions: this arena's na discrete actions (thrust == nullptr) or 2*na thrust floats
@@ -1592,13 +1752,37 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     RR_STAMP(8);
     uint32_t prev_moved = 0, snap_moved = 0;
     int snap_at = -2; // sub-step whose end state the snapshot holds
+    Hit fz = { 0, 0 }; // the frozen island (see substep)
 #pragma unroll 1
     for (int f = 0; f < RR_NUM_SUBSTEPS; f++) { // MOVES_PER_FRAME
         int work = 0;
-        substep(A, sp, naughty, st, prev_moved, work);
-        if (o.snap && work >= 3 && f + 1 < RR_NUM_SUBSTEPS && robots_unmoved(A)) { // expensive sub-step: has the arena stopped changing?
-            const bool same = snapshot_same_and_update(A, o.snap, o.isnap, snap_at == f - 1) && snap_moved == prev_moved;
-            if (same) { RR_TRACE("E fixed point after sub-step %d\n", f); break; } // sub-steps f+1.. would reproduce this state bit for bit
+        Hit hit = { 0, 0 };
+        substep(A, sp, naughty, st, prev_moved, work, fz, hit);
+        // An expensive sub-step: has the arena, or the island that made it expensive, stopped changing?  (The snapshot
+        // costs a round trip to the arena's HBM record, so it is only taken when a whole-arena fixed point is possible --
+        // no robot moved -- or when the sub-step exhausted the resolve loop.)
+        if (o.snap && f + 1 < RR_NUM_SUBSTEPS && ((C::NR > 1 && work >= 12) || (work >= 3 && robots_unmoved(A)))) {
+            uint32_t chg_r, chg_re, chg_b;
+            bool ax_diff;
+            const bool have = snap_at == f - 1;
+            snapshot_compare_update(A, o.snap, o.isnap, have, chg_r, chg_re, chg_b, ax_diff);
+            RR_TRACE("E snapshot at %d: have %d chg_r %x edges %x chg_b %x hit r %x b %x moved %x/%x work %d\n", f, (int)have, chg_r, chg_re, chg_b, hit.r, hit.b, prev_moved, snap_moved, work);
+            if (have) {
+                if (!(chg_r | chg_re | chg_b) && !ax_diff && snap_moved == prev_moved) {
+                    RR_TRACE("E fixed point after sub-step %d\n", f);
+                    break; // sub-steps f+1.. would reproduce this state bit for bit
+                }
+                // the island: everything that took part in a hit.  Unchanged since the previous sub-step, its robots'
+                // moves undone in both (so neither the ring update nor ax/ay/arot matter to it) -> freeze it.  A robot's
+                // AABB edges may keep drifting in the last bits (move + undo, incremental); nothing but the wall test of
+                // its own move reads them, so a robot clear of the walls may be frozen and its edge arithmetic replayed.
+                // (a one-robot arena is its own island: the whole-arena test above already covers it)
+                if (C::NR > 1 && (hit.r | hit.b) && !(chg_r & hit.r) && !(chg_b & hit.b) && !((prev_moved | snap_moved) & hit.r) &&
+                    robots_clear_of_walls(A, sp, hit.r)) {
+                    RR_TRACE("E freeze robots %x balls %x after sub-step %d\n", hit.r, hit.b, f);
+                    fz = hit;
+                }
+            }
             snap_at = f; snap_moved = prev_moved;
         }
     }

@@ -1,7 +1,12 @@
-"""The fixed-point shortcut of the sub-step loop (rr_sim.hpp, step_arena): when an expensive sub-step leaves the whole
-arena bit-identical to the sub-step before it, the remaining sub-steps are skipped.  It must be EXACT: the kernel's phase
-source (host-emulated wave) with the shortcut on and off has to produce bit-identical states, observations, rewards and
-status words over multi-step rollouts of stuck / contact-dense arenas -- and the shortcut has to fire on them."""
+"""The two exact shortcuts for stuck arenas (rr_sim.hpp: step_arena, substep):
+  * whole-arena fixed point -- an expensive sub-step leaves the arena bit-identical to the sub-step before it: the
+    remaining sub-steps are skipped;
+  * island freeze -- the entities that took part in the hits of an expensive sub-step are bit-identical to a sub-step
+    earlier: they are frozen (an obstacle with its recorded excursion) while the rest of the arena keeps stepping, and
+    thawed the moment anything outside comes within a broad-phase bound of them.
+Both must be EXACT: the kernel's phase source (host-emulated wave) with the shortcuts on and off has to produce
+bit-identical states, observations, rewards and status words over multi-step rollouts of stuck / contact-dense arenas
+-- and the shortcuts (freeze, both thaw points, fixed point) have to actually fire on them."""
 import io
 import os
 import sys
@@ -34,13 +39,13 @@ def _rollout(preset, robots, balls, actions, memo, steps, narrow=False, state=No
         el.lib().emu_debug_memo(1)
 
 
-def _count_fixed_points(fn):
-    """runs fn() with the emulation trace on and counts 'fixed point' lines on stderr (fd-level capture)."""
+def _count_events(fn, words=("fixed point",)):
+    """runs fn() with the emulation trace on and counts trace lines on stderr (captured at fd level into a file)."""
+    import tempfile
     sys.stderr.flush()
     saved = os.dup(2)
-    r, w = os.pipe()
-    os.dup2(w, 2)
-    os.close(w)
+    tf = tempfile.TemporaryFile()
+    os.dup2(tf.fileno(), 2)
     el.lib().emu_debug_trace(1)
     try:
         fn()
@@ -49,14 +54,14 @@ def _count_fixed_points(fn):
         sys.stderr.flush()
         os.dup2(saved, 2)
         os.close(saved)
-    chunks = []
-    while True:
-        b = os.read(r, 1 << 16)
-        if not b:
-            break
-        chunks.append(b)
-    os.close(r)
-    return b"".join(chunks).count(b"fixed point")
+    tf.seek(0)
+    out = tf.read()
+    tf.close()
+    return {w: out.count(w.encode()) for w in words}
+
+
+def _count_fixed_points(fn):
+    return _count_events(fn)["fixed point"]
 
 
 @pytest.mark.parametrize("preset,n,narrow", [("T", 240, False), ("T", 120, True), ("G", 60, False), ("G", 60, True)])
@@ -87,3 +92,55 @@ def test_shortcut_exact_on_the_squeezed_fixture_G():
     on = _rollout("G", None, None, d["actions"], True, 5, state=state)
     off = _rollout("G", None, None, d["actions"], False, 5, state=state)
     assert on == off
+
+
+def test_island_freeze_exact_on_stuck_islands_from_a_rollout_G():
+    """40 arenas taken from the slowest wavefronts of a 65,536-arena random rollout on the MI355X (a ball squeezed between
+    robots, robots pushing a ball into each other): the freeze fires on them and changes nothing."""
+    d = np.load(os.path.join(HERE, "data", "stuck_islands_G.npz"))
+    fired = {"freeze": 0, "thaw in phase 1": 0}
+    for a in range(len(d["step"])):
+        state = (d["robots"][a], d["robots_i"][a], d["balls"][a], int(d["step"][a]))
+        on = _rollout("G", None, None, d["actions"][a], True, 3, state=state)
+        off = _rollout("G", None, None, d["actions"][a], False, 3, state=state)
+        assert on == off, a
+        c = _count_events(lambda: _rollout("G", None, None, d["actions"][a], True, 3, state=state), tuple(fired))
+        for k in fired:
+            fired[k] += c[k]
+    assert fired["freeze"] >= 20, fired
+
+
+def test_island_thaw_paths_are_exact_G():
+    """The squeezed fixture with the other balls sent rolling at the island, at each other and at the walls, and the free
+    robots driven at random: the island must thaw in phase 1 (a robot / ball comes close before the roll) and in phase 2
+    (something turns up after the roll) and the results must not change by a bit."""
+    d = np.load(os.path.join(HERE, "..", "tools", "fixtures", "squeezed_G.npz"))
+    rng = np.random.RandomState(3)
+    isl = np.array([611.7, 324.6])
+    fired = {"freeze": 0, "thaw in phase 1": 0, "thaw in phase 2": 0}
+    for t in range(160):
+        balls = d["balls"].copy()
+        mode = t % 4
+        for b in (0, 1, 2, 4, 5, 6, 7):
+            if mode in (0, 1) and rng.rand() < 0.5:    # a free ball heading for / passing by the island
+                ang, dist = rng.uniform(0, 2 * np.pi), rng.uniform(20, 90)
+                pos = isl + dist * np.array([np.cos(ang), np.sin(ang)])
+                v = -(pos - isl) / dist * rng.uniform(0.5, 6) + rng.uniform(-1, 1, 2)
+            elif mode == 2 and rng.rand() < 0.5:        # free balls at the walls, far from the island
+                pos = np.array([rng.choice([rng.uniform(8, 20), rng.uniform(780, 792)]), rng.uniform(20, 780)])
+                v = rng.uniform(-5, 5, 2)
+            elif mode == 3 and b in (0, 1):             # two free balls running into each other
+                pos, v = np.array([200.0 + 10 * b, 600.0]), np.array([3.0 * (1 - 2 * b), 0.0])
+            else:
+                pos, v = balls[b, :2], rng.choice([0.0, 1.0]) * rng.uniform(-3, 3, 2)
+            balls[b] = [pos[0], pos[1], pos[0] - 7, pos[0] + 7, pos[1] - 7, pos[1] + 7, v[0], v[1]]
+        act = d["actions"].copy()
+        act[:2] = rng.randint(0, 8, 2)
+        state = (d["robots"], d["robots_i"], balls, int(d["step"]))
+        on = _rollout("G", None, None, act, True, 2, state=state)
+        off = _rollout("G", None, None, act, False, 2, state=state)
+        assert on == off, (t, mode)
+        c = _count_events(lambda: _rollout("G", None, None, act, True, 2, state=state), tuple(fired))
+        for k in fired:
+            fired[k] += c[k]
+    assert fired["freeze"] > 100 and fired["thaw in phase 1"] > 50 and fired["thaw in phase 2"] > 10, fired
