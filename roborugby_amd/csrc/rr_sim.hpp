@@ -1175,6 +1175,73 @@ RR_HDN void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real>
     }
 }
 
+// the two fast phases of a sub-step (see substep); FZ: an island is frozen
+template <class C, bool FZ>
+RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, const Hit &fz, uint32_t prev_moved, uint64_t &m_rr,
+                          uint64_t &m_br) {
+    using R = typename C::Real;
+    RR_FOR_LANES(l) {
+        bool c_rr = false, c_br = false;
+        if (l < C::NR && !(FZ && ((fz.r >> l) & 1u))) {
+            if (prev_moved & (1u << l)) { A.p.px[l] = A.ax[l]; A.p.py[l] = A.ay[l]; A.p.prot[l] = A.arot[l]; }
+            // on_frame_begin (RR_Robot.py:119-120): the ring entry written this frame
+            const R ox = A.p.rcx[l], oy = A.p.rcy[l];
+            A.ax[l] = ox; A.ay[l] = oy; A.arot[l] = A.p.rrot[l];
+            for (int j = 0; j < C::NR; j++) { // robot-robot: needs centres within 2 x 22.36 (+ 2 x 3 px of motion)
+                R dx = A.p.rcx[j] - ox, dy = A.p.rcy[j] - oy;
+                // each pair once (j > l); a frozen j has no lane of its own in this phase, so its partner tests the pair
+                c_rr = c_rr | (((j > l) | (FZ && ((fz.r >> j) & 1u) != 0)) & (j != l) & (dx * dx + dy * dy <= (R)(51.5 * 51.5)));
+            }
+            robot_move_lane(A, sp, l); // _move_bots
+        }
+        if (l < C::NB) {
+            if (!(FZ && ((fz.b >> l) & 1u))) { // on_frame_begin (RR_Ball.py:63-68)
+                A.bmass[l] = 1; A.bfx[l] = (R)0; A.bfy[l] = (R)0; A.exc[l] = (R)0;
+                A.pfx[l] = ball_copy_c<R>(A.p.bcx[l]); A.pfy[l] = ball_copy_c<R>(A.p.bcy[l]);
+                for (int r = 0; r < C::NR; r++) { // ball-robot: 22.36 + 9.9 (+ 3 px of robot motion)
+                    R dx = A.p.bcx[l] - A.p.rcx[r], dy = A.p.bcy[l] - A.p.rcy[r];
+                    c_br = c_br | (dx * dx + dy * dy <= (R)(36.0 * 36.0));
+                }
+            } else { // frozen ball: anywhere within its recorded excursion, against the robots outside the island
+                const R reach = (R)36.05 + A.exc[l];
+                for (int r = 0; r < C::NR; r++) {
+                    R dx = A.p.bcx[l] - A.p.rcx[r], dy = A.p.bcy[l] - A.p.rcy[r];
+                    c_br = c_br | ((((fz.r >> r) & 1u) == 0) & (dx * dx + dy * dy <= reach * reach));
+                }
+            }
+        }
+        RR_VOTE(m_rr, l, c_rr);
+        RR_VOTE(m_br, l, c_br);
+    }
+}
+template <class C, bool FZ>
+RR_HD void substep_phase2(Arena<C> &A, const SimParams<typename C::Real> &sp, const Hit &fz, uint64_t &m_any) {
+    using R = typename C::Real;
+    RR_FOR_LANES(l) {
+        bool c = false;
+        if (l < C::NB && !(FZ && ((fz.b >> l) & 1u))) {
+            ball_move_lane(A, l);
+            const R mx = A.p.bcx[l], my = A.p.bcy[l];
+            for (int j = 0; j < C::NB; j++) {
+                R dx = A.p.bcx[j] - mx, dy = A.p.bcy[j] - my;
+                R tr = (m_abs(A.p.bvx[j]) + m_abs(A.bfx[j]) + m_abs(A.p.bvy[j]) + m_abs(A.bfy[j])) * (R)1.01 + (R)0.02;
+                if (FZ) tr = ((fz.b >> j) & 1u) ? A.exc[j] + (R)0.02 : tr; // a frozen ball: wherever its island carried it
+                R reach = (R)14.04 + tr;
+                c = c | ((j != l) & (dx * dx + dy * dy <= reach * reach));
+            }
+            for (int r = 0; r < C::NR; r++) {
+                if (FZ && ((fz.r >> r) & 1u)) { // a frozen robot: its frame-begin or its (undone) moved pose -- the radius bound + 3 px
+                    R dx = mx - A.p.rcx[r], dy = my - A.p.rcy[r];
+                    c = c | (dx * dx + dy * dy <= (R)(36.0 * 36.0));
+                } else {
+                    c = c | ball_near_robot(A, l, r);
+                }
+            }
+            c = c | ball_collided_wall(A, sp, l);
+        }
+        RR_VOTE(m_any, l, c);
+    }
+}
 // _push_balls over a frozen hit list (RR_EnvBase.py:335-339), ball-major order
 template <class C>
 RR_HD void push_balls(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t br, uint32_t bots_moved, int &st, Hit &hit) {
@@ -1236,39 +1303,9 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     // it may see a robot centre from before or after this sub-step's move, so its bounds carry the largest centre
     // displacement a move can cause (1 px drive / 0.17 px pivot / <= 1.5 px wall clamp: 3 px per robot is generous).
     uint64_t m_rr = 0, m_br = 0;
-    RR_FOR_LANES(l) {
-        bool c_rr = false, c_br = false;
-        if (l < C::NR && !((fz.r >> l) & 1u)) {
-            if (prev_moved & (1u << l)) { A.p.px[l] = A.ax[l]; A.p.py[l] = A.ay[l]; A.p.prot[l] = A.arot[l]; }
-            // on_frame_begin (RR_Robot.py:119-120): the ring entry written this frame
-            const R ox = A.p.rcx[l], oy = A.p.rcy[l];
-            A.ax[l] = ox; A.ay[l] = oy; A.arot[l] = A.p.rrot[l];
-            for (int j = 0; j < C::NR; j++) { // robot-robot: needs centres within 2 x 22.36 (+ 2 x 3 px of motion)
-                R dx = A.p.rcx[j] - ox, dy = A.p.rcy[j] - oy;
-                // each pair once (j > l); a frozen j has no lane of its own in this phase, so its partner tests the pair
-                c_rr = c_rr | (((j > l) | (((fz.r >> j) & 1u) != 0)) & (j != l) & (dx * dx + dy * dy <= (R)(51.5 * 51.5)));
-            }
-            robot_move_lane(A, sp, l); // _move_bots
-        }
-        if (l < C::NB) {
-            if (!((fz.b >> l) & 1u)) { // on_frame_begin (RR_Ball.py:63-68)
-                A.bmass[l] = 1; A.bfx[l] = (R)0; A.bfy[l] = (R)0; A.exc[l] = (R)0;
-                A.pfx[l] = ball_copy_c<R>(A.p.bcx[l]); A.pfy[l] = ball_copy_c<R>(A.p.bcy[l]);
-                for (int r = 0; r < C::NR; r++) { // ball-robot: 22.36 + 9.9 (+ 3 px of robot motion)
-                    R dx = A.p.bcx[l] - A.p.rcx[r], dy = A.p.bcy[l] - A.p.rcy[r];
-                    c_br = c_br | (dx * dx + dy * dy <= (R)(36.0 * 36.0));
-                }
-            } else { // frozen ball: anywhere within its recorded excursion, against the robots outside the island
-                const R reach = (R)36.05 + A.exc[l];
-                for (int r = 0; r < C::NR; r++) {
-                    R dx = A.p.bcx[l] - A.p.rcx[r], dy = A.p.bcy[l] - A.p.rcy[r];
-                    c_br = c_br | ((((fz.r >> r) & 1u) == 0) & (dx * dx + dy * dy <= reach * reach));
-                }
-            }
-        }
-        RR_VOTE(m_rr, l, c_rr);
-        RR_VOTE(m_br, l, c_br);
-    }
+    const bool frozen = (fz.r | fz.b) != 0; // the frozen variants are separate instantiations: the common path pays nothing
+    if (frozen) substep_phase1<C, true>(A, sp, fz, prev_moved, m_rr, m_br);
+    else substep_phase1<C, false>(A, sp, fz, prev_moved, m_rr, m_br);
     RR_SYNC();
     RR_STAMP(1);
     if ((fz.r | fz.b) && (m_rr | m_br)) { // thaw before anything depended on the island
@@ -1292,30 +1329,8 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     // the most it can still travel (|v| + |force| per axis, +1 % and the 0.005 dead band for a velocity read after its
     // damping).  Ball-robot uses the settled robot centres; the wall test is the exact int-rect test.
     uint64_t m_any = 0;
-    RR_FOR_LANES(l) {
-        bool c = false;
-        if (l < C::NB && !((fz.b >> l) & 1u)) {
-            ball_move_lane(A, l);
-            const R mx = A.p.bcx[l], my = A.p.bcy[l];
-            for (int j = 0; j < C::NB; j++) {
-                R dx = A.p.bcx[j] - mx, dy = A.p.bcy[j] - my;
-                R tr = (m_abs(A.p.bvx[j]) + m_abs(A.bfx[j]) + m_abs(A.p.bvy[j]) + m_abs(A.bfy[j])) * (R)1.01 + (R)0.02;
-                tr = ((fz.b >> j) & 1u) ? A.exc[j] + (R)0.02 : tr; // a frozen ball: wherever its island carried it
-                R reach = (R)14.04 + tr;
-                c = c | ((j != l) & (dx * dx + dy * dy <= reach * reach));
-            }
-            for (int r = 0; r < C::NR; r++) {
-                if ((fz.r >> r) & 1u) { // a frozen robot: its frame-begin or its (undone) moved pose -- the radius bound + 3 px
-                    R dx = mx - A.p.rcx[r], dy = my - A.p.rcy[r];
-                    c = c | (dx * dx + dy * dy <= (R)(36.0 * 36.0));
-                } else {
-                    c = c | ball_near_robot(A, l, r);
-                }
-            }
-            c = c | ball_collided_wall(A, sp, l);
-        }
-        RR_VOTE(m_any, l, c);
-    }
+    if (frozen && (fz.r | fz.b)) substep_phase2<C, true>(A, sp, fz, m_any);
+    else substep_phase2<C, false>(A, sp, fz, m_any);
     RR_SYNC();
     RR_STAMP(4);
     if ((fz.r | fz.b) && m_any) { // thaw after the roll phase: the island catches up (move, push, roll), then the full path
