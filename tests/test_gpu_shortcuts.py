@@ -1,0 +1,113 @@
+"""GPU tests of the exact shortcuts and of the dispatch order (whole-arena fixed point, island freeze, slowest-first
+launch order): switching them off must not change one bit of any output, on stuck islands, on contact-dense synthetic
+states, and on a full-size rollout; and the stuck arenas must still agree with the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import adversarial as adv
+import oracle_lib as ol
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _env(n, preset, **env_vars):
+    import roborugby_amd as rr
+    old = {k: os.environ.get(k) for k in env_vars}
+    os.environ.update({k: str(v) for k, v in env_vars.items()})
+    try:
+        return rr.BatchedRoboRugbyEnv(n, preset=preset, seed=3, time_limit=False, auto_reset=False)  # switches are read at creation
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _run(env, state, actions, steps):
+    env.set_state(*state)
+    out = []
+    for _ in range(steps):
+        o, r, d, info = env.step_f64(actions)
+        st = env.get_state()
+        out.append([t.cpu().numpy().copy() for t in (o, r, d, info.adblGrumpyState, info.dblGrumpyScore, info.status,
+                                                     st["robots"], st["robots_i"], st["balls"], st["step"]) if t is not None])
+    return out
+
+
+def _same(a, b):
+    return all(np.array_equal(x, y, equal_nan=True) for sa, sb in zip(a, b) for x, y in zip(sa, sb))
+
+
+def test_stuck_islands_shortcuts_off_equals_on_and_match_oracle():
+    d = np.load(os.path.join(HERE, "data", "stuck_islands_G.npz"))
+    f = np.load(os.path.join(HERE, "..", "tools", "fixtures", "squeezed_G.npz"))
+    robots = np.concatenate([d["robots"], f["robots"][None]]); robots_i = np.concatenate([d["robots_i"], f["robots_i"][None]])
+    balls = np.concatenate([d["balls"], f["balls"][None]]); step = np.concatenate([d["step"], [f["step"]]]).astype(np.int32)
+    acts = np.concatenate([d["actions"], f["actions"][None]]).astype(np.int32)
+    n = len(step)
+    a_t = torch.as_tensor(acts, device="cuda")
+    on = _run(_env(n, "G"), (robots, robots_i, balls, step), a_t, 4)
+    off = _run(_env(n, "G", RR_NO_MEMO=1, RR_NO_ORDER=1), (robots, robots_i, balls, step), a_t, 4)
+    assert _same(on, off)
+    # first step against the oracle (fp64, same tolerance as the parity tests)
+    worst = 0.0
+    for a in range(n):
+        o = ol.OracleEnv("G")
+        o.set_state(robots[a], robots_i[a], balls[a], None, int(step[a]))
+        r = o.step(acts[a])
+        s = o.get_state()
+        if r["status"] & 63:
+            continue
+        worst = max(worst, float(np.nanmax(np.abs(s["robots"] - on[0][6][a]))), float(np.abs(s["balls"] - on[0][8][a]).max()),
+                    float(np.abs(r["obs"] - on[0][0][a]).max()))
+        assert np.array_equal(s["robots_i"], on[0][7][a])
+    assert worst < 1e-9, worst
+
+
+@pytest.mark.parametrize("preset", ["T", "G"])
+def test_contact_dense_states_shortcuts_off_equals_on(preset):
+    n = 1536
+    robots, balls, actions = adv.make_states(preset, n, seed=21)
+    import roborugby_amd as rr
+    outs = []
+    for sw in ({}, {"RR_NO_MEMO": 1, "RR_NO_ORDER": 1}):
+        env = _env(n, preset, **sw)
+        env.set_poses(robots, balls)
+        a_t = torch.as_tensor(actions, device="cuda")
+        res = []
+        for _ in range(5):  # the same action five times: robots keep pushing, islands form and freeze
+            o, r, d, info = env.step_f64(a_t)
+            st = env.get_state()
+            res.append([t.cpu().numpy().copy() for t in (o, r, d, info.status, st["robots"], st["robots_i"], st["balls"])])
+        outs.append(res)
+    assert _same(outs[0], outs[1])
+
+
+def test_full_size_rollout_independent_of_shortcuts_and_dispatch_order():
+    import roborugby_amd as rr
+    n = 65536
+    gen = torch.Generator(device="cuda"); gen.manual_seed(9)
+    acts = torch.randint(0, 8, (40, n, 4), generator=gen, device="cuda", dtype=torch.int32)
+    finals = []
+    for sw in ({}, {"RR_NO_MEMO": 1, "RR_NO_ORDER": 1}):
+        old = {k: os.environ.get(k) for k in sw}
+        os.environ.update({k: str(v) for k, v in sw.items()})
+        try:
+            env = rr.BatchedRoboRugbyEnv(n, preset="G", seed=0)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        env.reset()
+        rew = torch.zeros(n, device="cuda", dtype=torch.float64)
+        for s in range(40):
+            o, r, d, info = env.step(acts[s])
+            rew += r.double()
+        st = env.get_state()
+        finals.append((o.cpu().numpy(), rew.cpu().numpy(), st["robots"].cpu().numpy(), st["balls"].cpu().numpy(), st["robots_i"].cpu().numpy()))
+    for x, y in zip(*finals):
+        assert np.array_equal(x, y, equal_nan=True)
