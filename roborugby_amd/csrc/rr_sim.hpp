@@ -141,25 +141,27 @@ RR_HD float m_rint(float x) { return ::rintf(x); }
 // matters for corner offsets of length ~22; much cheaper in registers and instructions than the generic ocml
 // path with its Payne-Hanek fallback, and identical on the host emulation and on the GPU.
 RR_HD void m_sincos(double x, double &s, double &c) {
+    // explicit fused multiply-adds (the build runs with -ffp-contract=off so that the REFERENCE arithmetic is never
+    // contracted; this routine is ours, and fma is exactly specified, so GPU and host emulation still agree bit for bit)
     const double fn = ::rint(x * 6.36619772367581382433e-01);
     const int n = (int)fn;
-    const double z0 = x - fn * 1.57079632673412561417e+00; // pio2_1: first 33 bits of pi/2 (exact product)
-    const double w0 = fn * 6.07710050650619224932e-11;      // pio2_1t
+    const double z0 = ::fma(-fn, 1.57079632673412561417e+00, x); // pio2_1: first 33 bits of pi/2 (exact product)
+    const double w0 = fn * 6.07710050650619224932e-11;             // pio2_1t
     const double y = z0 - w0, yl = (z0 - y) - w0;
     const double z = y * y;
     // __kernel_sin(y, yl, 1)
     const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
                  S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
     const double v = z * y;
-    const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-    const double ks = y - ((z * (0.5 * yl - v * rs) - yl) - v * S1);
+    const double rs = ::fma(z, ::fma(z, ::fma(z, ::fma(z, S6, S5), S4), S3), S2);
+    const double ks = y - ::fma(-v, S1, ::fma(z, ::fma(0.5, yl, -v * rs), -yl));
     // __kernel_cos(y, yl)
     const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
                  C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
     const double w = z * z;
-    const double rc = z * (C1 + z * (C2 + z * C3)) + (w * w) * (C4 + z * (C5 + z * C6));
+    const double rc = ::fma(w * w, ::fma(z, ::fma(z, C6, C5), C4), z * ::fma(z, ::fma(z, C3, C2), C1));
     const double hz = 0.5 * z, wc = 1.0 - hz;
-    const double kc = wc + (((1.0 - wc) - hz) + (z * rc - y * yl));
+    const double kc = wc + (((1.0 - wc) - hz) + ::fma(z, rc, -y * yl));
     const int q = n & 3;
     s = (q == 0) ? ks : (q == 1) ? kc : (q == 2) ? -ks : -kc;
     c = (q == 0) ? kc : (q == 1) ? -ks : (q == 2) ? -kc : ks;
