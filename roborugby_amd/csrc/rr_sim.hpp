@@ -1477,6 +1477,113 @@ RR_HDN bool observe(Arena<C> &A, const SimParams<typename C::Real> &sp, int team
     return true;
 }
 
+// Both teams' default observations (own robot 0, positive ball 0) in ONE pass: the 2 x 3 x NR (ray, rect) lidar tasks share
+// their rounds, and the two scalar tails (angles, distances) run side by side in lanes 0 and 1 instead of one after the
+// other.  Same per-task arithmetic as observe().  The second team's candidates live in per-sub-step ball scratch that is
+// dead by now (bfx..pfy, exc).
+template <class C, typename O>
+RR_HDN void observe_both(Arena<C> &A, const SimParams<typename C::Real> &sp, O *out_h, O *out_g, int &st) {
+    using R = typename C::Real;
+    static_assert(C::NRH > 0 && C::NRG > 0, "two teams");
+    static_assert(6 * C::NR <= 4 * C::NB && 6 <= C::NB, "the second team's lidar scratch aliases bfx..pfy / exc");
+    static_assert(offsetof(ArenaBody<C>, pfy) == offsetof(ArenaBody<C>, bfx) + 3 * C::NB * sizeof(R), "bfx, bfy, pfx, pfy are contiguous");
+    constexpr int NT1 = 3 * C::NR;
+    R *cand[2][2] = { { A.u.lidar[0], A.u.lidar[1] }, { &A.bfx[0], &A.bfx[0] + NT1 } }; // [team][front|back][ray, rect]
+    R *lids[2] = { A.lid, A.exc };
+    RR_FOR_LANES(l) { if (l < C::NR) A.irot[l] = (R)NAN; } // the candidates below overwrite the aliased inner-square offsets
+    RR_SYNC();
+    ensure_sides(A);
+    for (int base = 0; base < 2 * NT1; base += C::VW) {
+        RR_FOR_LANES(l) {
+            const int t2 = base + l;
+            if (t2 < 2 * NT1) {
+                const int tm = t2 / NT1, t = t2 % NT1, ridx = tm == 0 ? 0 : C::NRH;
+                const int k = t / C::NR, j = t % C::NR;
+                int lst = 0;
+                V2<R> a, b; // ray start, end
+                if (k == 0) { // back-mid -> front-mid ; front = RIGHT side, back = LEFT side
+                    Seg<R> fr = robot_side(A, ridx, 0), bk = robot_side(A, ridx, 2);
+                    b = { (fr.a.x + fr.b.x) / (R)2, (fr.a.y + fr.b.y) / (R)2 };
+                    a = { (bk.a.x + bk.b.x) / (R)2, (bk.a.y + bk.b.y) / (R)2 };
+                } else if (k == 1) { a = robot_corner(A, ridx, BL); b = robot_corner(A, ridx, TR); }
+                else { a = robot_corner(A, ridx, TL); b = robot_corner(A, ridx, BR); }
+                R mr, cr;
+                slope_yint<R>(a, b, mr, cr, lst);
+                R bf = inf_<R>(), bb = inf_<R>();
+                const R hx = sp.W / (R)2, hy = sp.H / (R)2;
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    Seg<R> side;
+                    R ms, cs;
+                    if (j < C::NR - 1) {
+                        const int ro = j < ridx ? j : j + 1;
+                        side = robot_side(A, ro, s);
+                        ms = A.sm[ro][s]; cs = A.sc[ro][s];
+                    } else { // rect_walls = FloatRect(0, W, 0, H) (RR_EnvBase.py:74), see observe()
+                        const int ca = side_a(s), cb = side_b(s);
+                        side = { { hx + ((ca & 1) ? hx : -hx), hy + ((ca & 2) ? hy : -hy) },
+                                 { hx + ((cb & 1) ? hx : -hx), hy + ((cb & 2) ? hy : -hy) } };
+                        ms = s == 0 ? inf_<R>() : s == 2 ? -inf_<R>() : s == 1 ? (R)0 : (R)-0.0;
+                        cs = s == 0 ? -inf_<R>() : s == 2 ? inf_<R>() : s == 1 ? (R)0 : sp.H;
+                    }
+                    V2<R> I = intersect_mb<R>(ms, cs, side.a.x, mr, cr, a.x);
+                    R de = dist<R>(I, b), ds = dist<R>(I, a);
+                    if (de <= ds && de < bf) bf = de;
+                    if (ds <= de && ds < bb) bb = ds;
+                }
+                cand[tm][0][t] = bf;
+                cand[tm][1][t] = bb;
+            }
+        }
+    }
+    RR_SYNC();
+    for (int base = 0; base < 12; base += C::VW) {
+        RR_FOR_LANES(l) { // min over the rects: one lane per (team, ray, direction)
+            const int t2 = base + l;
+            if (t2 < 12) {
+                const int tm = t2 / 6, t = t2 % 6;
+                const R *src = cand[tm][t & 1];
+                const int k = t >> 1;
+                R best = inf_<R>();
+                for (int q = 0; q < C::NR; q++) {
+                    R v = src[k * C::NR + q];
+                    if (v < best) best = v;
+                }
+                lids[tm][t] = py_min<R>(best, (R)150);
+            }
+        }
+    }
+    RR_SYNC();
+    uint64_t any_div0 = 0;
+    RR_FOR_LANES(l) { // the scalar tails of the two teams, side by side
+        int lst = 0;
+        if (l < 2) {
+            const int ridx = l == 0 ? 0 : C::NRH;
+            O *out = l == 0 ? out_h : out_g;
+            const R *lid = lids[l];
+            V2<R> rc = { A.p.rcx[ridx], A.p.rcy[ridx] }, bc = { A.p.bcx[0], A.p.bcy[0] };
+            V2<R> good = { sp.W, sp.H }, bad = { (R)0, (R)0 };
+            R ball_angle = angle_degrees<R>(rc, bc, lst);
+            R ball_dist = py_min<R>(dist<R>(rc, bc), (R)150);
+            R goal_angle = angle_degrees<R>(rc, good, lst);
+            R bot_angle = A.p.rrot[ridx];
+            R dbad = dist<R>(rc, bad), dgood = dist<R>(rc, good);
+            R goal_dist = (dgood <= dbad) ? py_min<R>(dgood, (R)390) : (R)-1 * py_min<R>(dbad, (R)390);
+            if (l == 1) { // GRUMPY looking at a positive ball (RR_Observers.py:386-392)
+                goal_dist *= (R)-1;
+                ball_angle = py_mod<R>(ball_angle + (R)180, (R)360);
+                goal_angle = py_mod<R>(goal_angle + (R)180, (R)360);
+                bot_angle = py_mod<R>(bot_angle + (R)180, (R)360);
+            }
+            out[0] = (O)bot_angle; out[1] = (O)ball_angle; out[2] = (O)ball_dist; out[3] = (O)goal_angle; out[4] = (O)goal_dist;
+            out[5] = (O)lid[0]; out[6] = (O)lid[2]; out[7] = (O)lid[4]; out[8] = (O)lid[1]; out[9] = (O)lid[5]; out[10] = (O)lid[3];
+        }
+        RR_VOTE(any_div0, l, (lst & ST_DIV0) != 0);
+    }
+    if (any_div0) st |= ST_DIV0;
+    RR_SYNC();
+}
+
 // ------------------------------------------------------------------------------------------------ derived data, clean poses
 // scratch that is a pure function of the persistent record: corner offsets of every pose in it
 template <class C> RR_HD void derive(Arena<C> &A, const SimParams<typename C::Real> &sp) {
@@ -1840,10 +1947,15 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     constexpr int ST_FATAL = ST_BOT_RESOLVE_FAIL | ST_BOT_STUCK | ST_UNDO_MOVE_FAIL | ST_UNDO_FAIL | ST_SAME_SPOT | ST_DIV0;
     const bool faulted = sp.reset_on_fault && (st & ST_FATAL); // the reference raised (or hangs) inside this step
     const bool done = is_done<R>(step_now, sp) || faulted;
-    observe<C, O>(A, sp, 1, -1, -1, o.obs, st);
-    if (o.obs_g) {
-        if (!observe<C, O>(A, sp, -1, -1, -1, o.obs_g, st)) {
-            for (int base = 0; base < 11; base += C::VW) { RR_FOR_LANES(l) { if (base + l < 11) o.obs_g[base + l] = (O)NAN; } }
+    if constexpr (C::NRH > 0 && C::NRG > 0) {
+        if (o.obs_g) observe_both<C, O>(A, sp, o.obs, o.obs_g, st);
+        else observe<C, O>(A, sp, 1, -1, -1, o.obs, st);
+    } else {
+        observe<C, O>(A, sp, 1, -1, -1, o.obs, st);
+        if (o.obs_g) {
+            if (!observe<C, O>(A, sp, -1, -1, -1, o.obs_g, st)) {
+                for (int base = 0; base < 11; base += C::VW) { RR_FOR_LANES(l) { if (base + l < 11) o.obs_g[base + l] = (O)NAN; } }
+            }
         }
     }
     if (RR_IS_LANE0) {
