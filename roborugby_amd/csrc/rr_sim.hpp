@@ -64,6 +64,9 @@
 // a per-lane value that lives across two lane-parallel phases: a plain register here, an array in the host emulation
 #define RR_LANE_VAR(type, name) type name
 #define RR_LV(name, l) name
+// the same variable in the neighbouring lane (l ^ 1): one DPP move per dword, no LDS.  Every lane of the pair must
+// execute it (DPP does not read lanes that EXEC has switched off), so it is only used at converged points.
+#define RR_XOR1(name, l) rr::lane_xor1(name)
 #else
 #define RR_FOR_LANES(l) for (int l = 0; l < C::VW; ++l)
 #define RR_IS_LANE0 true
@@ -71,6 +74,7 @@
 #define RR_VOTE(mask, l, pred) (mask) |= ((uint64_t)((pred) ? 1 : 0)) << (l)
 #define RR_LANE_VAR(type, name) type name[C::VW]
 #define RR_LV(name, l) name[l]
+#define RR_XOR1(name, l) name[(l) ^ 1]
 #endif
 
 // Diagnostic build only (-DRR_PROFILE_PHASES): per-phase cycle totals of the leader lane of every 64th wavefront,
@@ -115,6 +119,14 @@ template <int VW> __device__ __forceinline__ uint64_t vballot(bool pred) {
     if (VW == 64) return m;
     const int sh = (int)(threadIdx.x & 63 & ~(VW - 1));
     return (m >> sh) & ((1ull << (VW & 63)) - 1ull);
+}
+#endif
+
+#if RR_GPU
+__device__ __forceinline__ int lane_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true); }
+__device__ __forceinline__ float lane_xor1(float v) { return __int_as_float(lane_xor1(__float_as_int(v))); }
+__device__ __forceinline__ double lane_xor1(double v) {
+    return __hiloint2double(lane_xor1(__double2hiint(v)), lane_xor1(__double2loint(v)));
 }
 #endif
 
@@ -375,17 +387,22 @@ template <typename R> RR_HD void fr_set_cy(FR<R> &f, R v) { fr_move<R>(f, (R)0, 
 
 // body of the rotation setter (MyUtils.py:284-316): rotate the initial corners (+-hw, +-hh) by
 // 360-rot degrees and renormalise them to the corner distance
+// one corner of the rotation setter (MyUtils.py:284-316): the initial corner (ix, iy) rotated by (s, c) = sin/cos of
+// radians(360 - rot) and renormalised to the corner distance; rot == 0 keeps the initial corner (MyUtils.py:298-300)
+template <typename R> RR_HD void corner_from_sc(R rot, R s, R c, R ix, R iy, R cdist, R &ax, R &ay) {
+    R qx = ix * c - iy * s, qy = ix * s + iy * c;
+    R d = m_sqrt(qx * qx + qy * qy);
+    ax = qx * cdist / d; ay = qy * cdist / d;
+    const bool z = rot == (R)0;
+    ax = z ? ix : ax; ay = z ? iy : ay;
+}
 template <typename R> RR_HD void corners_from_sc(R rot, R s, R c, R hw, R hh, R cdist, R *rel) {
     // initial corners TL(-hw,-hh) TR(hw,-hh) BL(-hw,hh) BR(hw,hh): BR = -TL and BL = -TR, and every operation
-    // below is odd-symmetric in (x,y), so two corners are computed and two are exact negations
-    // (s, c) = sin/cos of radians(360 - rot); rot == 0 keeps the initial corners (MyUtils.py:298-300)
+    // is odd-symmetric in (x,y), so two corners are computed and two are exact negations
     const R ix[2] = { -hw, hw }, iy = -hh; // TL, TR
     for (int k = 0; k < 2; k++) {
-        R qx = ix[k] * c - iy * s, qy = ix[k] * s + iy * c;
-        R d = m_sqrt(qx * qx + qy * qy);
-        R ax = qx * cdist / d, ay = qy * cdist / d;
-        const bool z = rot == (R)0;
-        ax = z ? ix[k] : ax; ay = z ? iy : ay;
+        R ax, ay;
+        corner_from_sc<R>(rot, s, c, ix[k], iy, cdist, ax, ay);
         rel[2 * k] = ax; rel[2 * k + 1] = ay;                  // TL / TR
         rel[2 * (3 - k)] = -ax; rel[2 * (3 - k) + 1] = -ay;    // BR / BL
     }
@@ -459,42 +476,53 @@ template <typename R> RR_HD void rob_clamp(FR<R> &f, const SimParams<R> &sp) {
 // of three serialised divergent paths -- and the cheap bookkeeping then selects what its move type uses.  Every
 // value is computed from the same operands in the same order as Robot._move_linear / _move_angular
 // (RR_Robot.py:181-234): wall test on the incrementally kept edges, revert of centre (and rotation), 0.5 clamp.
-template <class C> RR_HD void robot_move_lane(Arena<C> &A, const SimParams<typename C::Real> &sp, int r) {
+// thrust pattern -> kind of move and the three angles whose sin/cos it can need
+template <typename R> struct MovePlan { bool idle, lin, spin; int L; R off, nrot, a1, a2, a3; };
+template <class C> RR_HD MovePlan<typename C::Real> robot_move_plan(const Arena<C> &A, int r) {
     using R = typename C::Real;
+    MovePlan<R> m;
     const int L = A.i.thl[r], Rt = A.i.thr[r];
-    A.i.mc[r] += 1;
-    if (L == Rt && L == 0) return;
+    const R rot = A.p.rrot[r];
+    m.L = L;
+    m.idle = (L == Rt && L == 0);
+    m.lin = (L == Rt);
+    m.spin = !m.lin && (L + Rt == 0);
+    const R w = m.lin ? (R)0 : m.spin ? (Rt > 0 ? (R)1.2 : (R)-1.2) : ((Rt > 0 || L < 0) ? (R).6 : (R)-.6);
+    m.off = (Rt != 0) ? (R)90 : (R)-90; // pivot = left track (rot+90) when the right one drives
+    m.nrot = m.lin ? rot : py_mod<R>((rot + w) + (R)720, (R)360);
+    m.a1 = m.lin ? rot : rot + m.off;   // heading (linear) / direction of the pivot (track) centre
+    m.a2 = (R)360 - m.nrot;             // rotation setter
+    m.a3 = m.nrot + -m.off;             // robot centre as seen from the pivot after the turn
+    return m;
+}
+// the move itself once the trigonometry is there: (s1,c1), (s3,c3) and the new TL / TR corner offsets for nrot
+template <class C>
+RR_HD void robot_move_finish(Arena<C> &A, const SimParams<typename C::Real> &sp, int r, const MovePlan<typename C::Real> &m,
+                             typename C::Real s1, typename C::Real c1, typename C::Real s3, typename C::Real c3,
+                             typename C::Real tlx, typename C::Real tly, typename C::Real trx, typename C::Real try_) {
+    using R = typename C::Real;
     FR<R> f = load_robot(A, r);
-    const bool lin = (L == Rt);
-    const bool spin = !lin && (L + Rt == 0);
-    const R w = lin ? (R)0 : spin ? (Rt > 0 ? (R)1.2 : (R)-1.2) : ((Rt > 0 || L < 0) ? (R).6 : (R)-.6);
-    const R off = (Rt != 0) ? (R)90 : (R)-90; // pivot = left track (rot+90) when the right one drives
-    const R nrot = lin ? f.rot : py_mod<R>((f.rot + w) + (R)720, (R)360);
-    R s1, c1, s2, c2, s3, c3;
-    m_sincos(radians<R>(lin ? f.rot : f.rot + off), s1, c1); // heading (linear) / direction of the pivot (track) centre
-    m_sincos(radians<R>((R)360 - nrot), s2, c2);              // rotation setter
-    m_sincos(radians<R>(nrot + -off), s3, c3);                // robot centre as seen from the pivot after the turn
     const R rot_prior = f.rot, px = f.cx, py = f.cy;
-    if (lin) {
-        const R vel = L < 0 ? (R)-1 : (R)1;
+    if (m.lin) {
+        const R vel = m.L < 0 ? (R)-1 : (R)1;
         fr_set_left<R>(f, f.l + c1 * vel);
         fr_set_top<R>(f, f.t + s1 * vel * (R)-1);
         if (rob_hit_wall<R>(f, sp)) { fr_set_cx<R>(f, px); fr_set_cy<R>(f, py); }
     } else {
-        if (nrot != f.rot) {
-            f.rot = nrot;
-            corners_from_sc<R>(nrot, s2, c2, (R)10, (R)20, sp.rob_cdist, f.rel);
+        if (m.nrot != f.rot) {
+            f.rot = m.nrot;
+            f.rel[0] = tlx; f.rel[1] = tly; f.rel[2] = trx; f.rel[3] = try_;       // TL, TR
+            f.rel[4] = -trx; f.rel[5] = -try_; f.rel[6] = -tlx; f.rel[7] = -tly;   // BL = -TR, BR = -TL
             fr_edges_from_rel<R>(f);
         }
-        if (!spin) {
+        if (!m.spin) {
             const R cpx = px + (R)16 * c1, cpy = py - (R)16 * s1; // tplCenterRot, from the pose before the turn
             fr_set_cx<R>(f, cpx + (R)16 * c3);
             fr_set_cy<R>(f, cpy - (R)16 * s3);
         }
         if (rob_hit_wall<R>(f, sp)) {
             fr_set_cx<R>(f, px); fr_set_cy<R>(f, py);
-            // `self.rectDbl.rotation = dblPriorRot` (RR_Robot.py:226): the setter on (rot_prior + 720) % 360.  With 32 robots
-            // per wavefront some robot is blocked by a wall while turning in most sub-steps, so this path is hot.  The
+            // `self.rectDbl.rotation = dblPriorRot` (RR_Robot.py:226): the setter on (rot_prior + 720) % 360.  The
             // normalised value is almost always rot_prior itself (it came out of this very normalisation one move ago),
             // and then the corners the setter would rebuild are the ones still sitting in LDS: A.rel is always
             // corners_for(rrot) and store_robot has not run yet.  Only a value the +720 really perturbs pays the trig.
@@ -512,6 +540,22 @@ template <class C> RR_HD void robot_move_lane(Arena<C> &A, const SimParams<typen
     }
     rob_clamp<R>(f, sp);
     store_robot(A, r, f);
+}
+// one robot's whole move on one lane (thaw / edge replay of the island freeze, and configurations without a lane pair
+// per robot); substep_phase1 spreads the same arithmetic over a pair of lanes
+template <class C> RR_HD void robot_move_lane(Arena<C> &A, const SimParams<typename C::Real> &sp, int r) {
+    using R = typename C::Real;
+    const MovePlan<R> m = robot_move_plan(A, r);
+    A.i.mc[r] += 1;
+    if (m.idle) return;
+    R s1, c1, s2, c2, s3, c3;
+    m_sincos(radians<R>(m.a1), s1, c1);
+    m_sincos(radians<R>(m.a2), s2, c2);
+    m_sincos(radians<R>(m.a3), s3, c3);
+    R tlx, tly, trx, try_;
+    corner_from_sc<R>(m.nrot, s2, c2, (R)-10, (R)-20, sp.rob_cdist, tlx, tly);
+    corner_from_sc<R>(m.nrot, s2, c2, (R)10, (R)-20, sp.rob_cdist, trx, try_);
+    robot_move_finish(A, sp, r, m, s1, c1, s3, c3, tlx, tly, trx, try_);
 }
 // Robot.undo_move (RR_Robot.py:110-137): back to the pose stored at frame begin
 template <class C> RR_HD void robot_undo_lane(Arena<C> &A, const SimParams<typename C::Real> &sp, int r) {
@@ -1182,38 +1226,82 @@ template <class C, bool FZ>
 RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, const Hit &fz, uint32_t prev_moved, uint64_t &m_rr,
                           uint64_t &m_br) {
     using R = typename C::Real;
+    // A robot's move is spread over a PAIR of lanes (2r, 2r+1) when the virtual wave has them: both lanes run the same
+    // instructions on different data -- two of the three sin/cos evaluations at once, then one renormalised corner each --
+    // and swap results through DPP.  Same operations on the same operands as robot_move_lane; ~30 % fewer instructions.
+    constexpr bool PAIRED = C::VW >= 2 * C::NR;
+    RR_LANE_VAR(R, sv); RR_LANE_VAR(R, cv); // sin / cos of this lane's angle: a1 on the even lane, a2 on the odd one
+    RR_LANE_VAR(R, qx); RR_LANE_VAR(R, qy); // this lane's corner: TL on the even lane, TR on the odd one
+    RR_LANE_VAR(MovePlan<R>, mp);           // the robot's move plan (both lanes of the pair hold a copy)
     RR_FOR_LANES(l) {
         bool c_rr = false, c_br = false;
-        if (l < C::NR && !(FZ && ((fz.r >> l) & 1u))) {
-            if (prev_moved & (1u << l)) { A.p.px[l] = A.ax[l]; A.p.py[l] = A.ay[l]; A.p.prot[l] = A.arot[l]; }
+        const int r = PAIRED ? (l >> 1) : l, part = PAIRED ? (l & 1) : 0;
+        const bool robot_lane = r < C::NR && !(FZ && ((fz.r >> (r < C::NR ? r : 0)) & 1u));
+        if (robot_lane && part == 0) {
+            if (prev_moved & (1u << r)) { A.p.px[r] = A.ax[r]; A.p.py[r] = A.ay[r]; A.p.prot[r] = A.arot[r]; }
             // on_frame_begin (RR_Robot.py:119-120): the ring entry written this frame
-            const R ox = A.p.rcx[l], oy = A.p.rcy[l];
-            A.ax[l] = ox; A.ay[l] = oy; A.arot[l] = A.p.rrot[l];
+            const R ox = A.p.rcx[r], oy = A.p.rcy[r];
+            A.ax[r] = ox; A.ay[r] = oy; A.arot[r] = A.p.rrot[r];
             for (int j = 0; j < C::NR; j++) { // robot-robot: needs centres within 2 x 22.36 (+ 2 x 3 px of motion)
                 R dx = A.p.rcx[j] - ox, dy = A.p.rcy[j] - oy;
-                // each pair once (j > l); a frozen j has no lane of its own in this phase, so its partner tests the pair
-                c_rr = c_rr | (((j > l) | (FZ && ((fz.r >> j) & 1u) != 0)) & (j != l) & (dx * dx + dy * dy <= (R)(51.5 * 51.5)));
+                // each pair once (j > r); a frozen j has no lane of its own in this phase, so its partner tests the pair
+                c_rr = c_rr | (((j > r) | (FZ && ((fz.r >> j) & 1u) != 0)) & (j != r) & (dx * dx + dy * dy <= (R)(51.5 * 51.5)));
             }
-            robot_move_lane(A, sp, l); // _move_bots
+            if (!PAIRED) robot_move_lane(A, sp, r); // _move_bots
+        }
+        if (PAIRED) {
+            R s_ = (R)0, c_ = (R)1;
+            if (robot_lane) {
+                const MovePlan<R> m = robot_move_plan(A, r);
+                m_sincos(radians<R>(part == 0 ? m.a1 : m.a2), s_, c_);
+                RR_LV(mp, l) = m;
+            }
+            RR_LV(sv, l) = s_; RR_LV(cv, l) = c_;
         }
         if (l < C::NB) {
             if (!(FZ && ((fz.b >> l) & 1u))) { // on_frame_begin (RR_Ball.py:63-68)
                 A.bmass[l] = 1; A.bfx[l] = (R)0; A.bfy[l] = (R)0; A.exc[l] = (R)0;
                 A.pfx[l] = ball_copy_c<R>(A.p.bcx[l]); A.pfy[l] = ball_copy_c<R>(A.p.bcy[l]);
-                for (int r = 0; r < C::NR; r++) { // ball-robot: 22.36 + 9.9 (+ 3 px of robot motion)
-                    R dx = A.p.bcx[l] - A.p.rcx[r], dy = A.p.bcy[l] - A.p.rcy[r];
+                for (int r2 = 0; r2 < C::NR; r2++) { // ball-robot: 22.36 + 9.9 (+ 3 px of robot motion)
+                    R dx = A.p.bcx[l] - A.p.rcx[r2], dy = A.p.bcy[l] - A.p.rcy[r2];
                     c_br = c_br | (dx * dx + dy * dy <= (R)(36.0 * 36.0));
                 }
             } else { // frozen ball: anywhere within its recorded excursion, against the robots outside the island
                 const R reach = (R)36.05 + A.exc[l];
-                for (int r = 0; r < C::NR; r++) {
-                    R dx = A.p.bcx[l] - A.p.rcx[r], dy = A.p.bcy[l] - A.p.rcy[r];
-                    c_br = c_br | ((((fz.r >> r) & 1u) == 0) & (dx * dx + dy * dy <= reach * reach));
+                for (int r2 = 0; r2 < C::NR; r2++) {
+                    R dx = A.p.bcx[l] - A.p.rcx[r2], dy = A.p.bcy[l] - A.p.rcy[r2];
+                    c_br = c_br | ((((fz.r >> r2) & 1u) == 0) & (dx * dx + dy * dy <= reach * reach));
                 }
             }
         }
         RR_VOTE(m_rr, l, c_rr);
         RR_VOTE(m_br, l, c_br);
+    }
+    if (PAIRED) {
+        // (the broad phase above read robot centres that no lane has moved yet: its bounds hold a fortiori)
+        RR_FOR_LANES(l) { // the rotation setter's sin/cos sits in the odd lane: both lanes need it for their corner
+            const int r = l >> 1, part = l & 1;
+            const R ps = RR_XOR1(sv, l), pc = RR_XOR1(cv, l);
+            const R s2 = part ? RR_LV(sv, l) : ps, c2 = part ? RR_LV(cv, l) : pc;
+            R ax = (R)0, ay = (R)0;
+            if (r < C::NR && !(FZ && ((fz.r >> (r < C::NR ? r : 0)) & 1u))) {
+                corner_from_sc<R>(RR_LV(mp, l).nrot, s2, c2, part ? (R)10 : (R)-10, (R)-20, sp.rob_cdist, ax, ay);
+            }
+            RR_LV(qx, l) = ax; RR_LV(qy, l) = ay;
+        }
+        RR_FOR_LANES(l) {
+            const int r = l >> 1, part = l & 1;
+            const R trx = RR_XOR1(qx, l), try_ = RR_XOR1(qy, l); // the odd lane's corner (TR), seen from the even lane
+            if (part == 0 && r < C::NR && !(FZ && ((fz.r >> (r < C::NR ? r : 0)) & 1u))) {
+                const MovePlan<R> m = RR_LV(mp, l);
+                A.i.mc[r] += 1;
+                if (!m.idle) {
+                    R s3, c3;
+                    m_sincos(radians<R>(m.a3), s3, c3);
+                    robot_move_finish(A, sp, r, m, RR_LV(sv, l), RR_LV(cv, l), s3, c3, RR_LV(qx, l), RR_LV(qy, l), trx, try_);
+                }
+            }
+        }
     }
 }
 template <class C, bool FZ>
