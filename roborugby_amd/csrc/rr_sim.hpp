@@ -326,7 +326,8 @@ template <class C> struct ArenaBody {
         int32_t step, episode, ep_len, ep_count, last_len, fault;
     } i;
     // ---- per-step scratch
-    R rel[NR][8];   // corner offsets TL,TR,BL,BR (x,y) for the current rotation
+    // (rows of 9, not 8: a 16-word row stride would put every robot's row of every arena of a bank group on the same 4 banks)
+    R rel[NR][9];   // corner offsets TL,TR,BL,BR (x,y) for the current rotation
     R irot[NR];     // rotation irel was built for (NaN = stale)
     R sm[NR][4], sc[NR][4]; // slope / y-intercept of the four sides (get_slope_yint, MyUtils.py:44-58) for the current pose
     R ax[NR], ay[NR], arot[NR]; // pose at frame begin (= ring entry written this frame)
@@ -337,7 +338,7 @@ template <class C> struct ArenaBody {
     R exc[NB];                // how far (L1) the contact responses of this sub-step have carried the ball from its frame-begin centre
     int32_t sides_ok; // sm/sc match the current robot poses (rebuilt lazily by the first phase that needs them)
     union { // the lidar candidates are only alive inside observe(), the inner-square offsets only inside a sub-step
-        R irel[NR][8];                    // corner offsets of the ball's inner square at rot+45 (diameter end points)
+        R irel[NR][9];                    // corner offsets of the ball's inner square at rot+45 (diameter end points)
         R lidar[2][3 * NR];               // [front|back][ray, rect] minima over the rect's four sides
     } u;
     R lid[6];                             // capped minima: front/back per ray
