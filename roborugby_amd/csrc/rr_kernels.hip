@@ -86,13 +86,17 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
     load_record(A, rec, irec);
     derive(A, sp);
     RR_STAMP(12);
-    StepOut<O> o = { obs + (size_t)arena * 11, obs_g ? obs_g + (size_t)arena * 11 : nullptr, reward + arena,
-                     reward_g ? reward_g + arena : nullptr, done + arena, status ? status + arena : nullptr,
-                     sp.memo ? reinterpret_cast<uint32_t *>(rec) : nullptr, irec };
+    StepOut<O> o = { obs, obs_g, reward, reward_g, done, status, sp.memo ? reinterpret_cast<uint32_t *>(recs) : nullptr, irecs, arena,
+                     (int)(Arena<C>::P_STRIDE * sizeof(typename C::Real) / 4), (int)Arena<C>::I_STRIDE };
     step_arena<C, O>(A, sp, sp.arena_offset + (uint64_t)arena, actions ? actions + (size_t)arena * na : nullptr,
                      thrust ? thrust + (size_t)arena * 2 * na : nullptr, na, o);
     RR_TR();
-    store_record(A, rec, irec);
+    {   // the record addresses again, from an arena index the optimiser cannot tie to the first one: otherwise the two
+        // 64-bit pointers stay live across the whole step (4 VGPRs of a kernel that sits at the 256-VGPR limit)
+        int arena_again = arena;
+        asm volatile("" : "+v"(arena_again));
+        store_record(A, recs + (size_t)arena_again * Arena<C>::P_STRIDE, irecs + (size_t)arena_again * Arena<C>::I_STRIDE);
+    }
     RR_STAMP(13);
     if (cost && threadIdx.x == 0) { // what this group cost, in shader clocks / 256 (saturating): next step's dispatch key
         const unsigned long long dt = (__builtin_amdgcn_s_memtime() - t_begin) >> 8;

@@ -1795,12 +1795,24 @@ RR_HDN void reset_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint
 template <typename R> RR_HD bool is_done(int step, const SimParams<R> &sp) {
     return sp.time_limit ? (step >= sp.game_len) : (step > sp.game_len); // TimeLimit wrapper vs raw :555-559
 }
+// Output slots of one arena: uniform base pointers + the arena index.  The per-arena addresses are formed at the point of
+// use -- carried as ready-made pointers they cost ~16 VGPRs across the whole sub-step loop and pushed the kernel into spills.
 template <typename O> struct StepOut {
-    O *obs, *obs_g, *reward, *reward_g;
-    uint8_t *done;
-    int32_t *status;
-    uint32_t *snap = nullptr;  // >= sizeof(Arena::P)/4 words of scratch for the fixed-point check (the arena's HBM record), or null
-    int32_t *isnap = nullptr;  // >= NR words
+    O *obs_base, *obs_g_base, *reward_base, *reward_g_base;
+    uint8_t *done_base;
+    int32_t *status_base;
+    uint32_t *snap_base = nullptr; // the arena records in HBM: scratch for the fixed-point check (null: shortcuts off)
+    int32_t *isnap_base = nullptr;
+    int arena = 0;
+    int snap_stride = 0, isnap_stride = 0; // words per arena
+    RR_HD O *obs() const { return obs_base + (size_t)arena * 11; }
+    RR_HD O *obs_g() const { return obs_g_base ? obs_g_base + (size_t)arena * 11 : nullptr; }
+    RR_HD O *reward() const { return reward_base + arena; }
+    RR_HD O *reward_g() const { return reward_g_base ? reward_g_base + arena : nullptr; }
+    RR_HD uint8_t *done() const { return done_base + arena; }
+    RR_HD int32_t *status() const { return status_base ? status_base + arena : nullptr; }
+    RR_HD uint32_t *snap() const { return snap_base ? snap_base + (size_t)arena * snap_stride : nullptr; }
+    RR_HD int32_t *isnap() const { return isnap_base + (size_t)arena * isnap_stride; }
 };
 
 // Fixed point of the sub-step map.  A stuck arena -- a ball squeezed between two robots, a robot pushing a ball into
@@ -1900,30 +1912,30 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
         if (sp.auto_reset) {
             reset_arena(A, sp, arena_gid, (uint64_t)(uint32_t)(A.i.episode + 1), st);
             st |= ST_WAS_RESET;
-            observe<C, O>(A, sp, 1, -1, -1, o.obs, st);
-            if (o.obs_g) {
-                if (!observe<C, O>(A, sp, -1, -1, -1, o.obs_g, st)) {
-                    for (int base = 0; base < 11; base += C::VW) { RR_FOR_LANES(l) { if (base + l < 11) o.obs_g[base + l] = (O)NAN; } }
+            observe<C, O>(A, sp, 1, -1, -1, o.obs(), st);
+            if (o.obs_g()) {
+                if (!observe<C, O>(A, sp, -1, -1, -1, o.obs_g(), st)) {
+                    for (int base = 0; base < 11; base += C::VW) { RR_FOR_LANES(l) { if (base + l < 11) o.obs_g()[base + l] = (O)NAN; } }
                 }
             }
             if (RR_IS_LANE0) {
-                *o.reward = (O)0; *o.done = 0;
-                if (o.reward_g) *o.reward_g = (O)0;
-                if (o.status) *o.status = st;
+                *o.reward() = (O)0; *o.done() = 0;
+                if (o.reward_g()) *o.reward_g() = (O)0;
+                if (o.status()) *o.status() = st;
             }
             return;
         }
         st |= ST_STEP_AFTER_DONE;
-        observe<C, O>(A, sp, 1, -1, -1, o.obs, st);
-        if (o.obs_g) {
-            if (!observe<C, O>(A, sp, -1, -1, -1, o.obs_g, st)) {
-                for (int base = 0; base < 11; base += C::VW) { RR_FOR_LANES(l) { if (base + l < 11) o.obs_g[base + l] = (O)NAN; } }
+        observe<C, O>(A, sp, 1, -1, -1, o.obs(), st);
+        if (o.obs_g()) {
+            if (!observe<C, O>(A, sp, -1, -1, -1, o.obs_g(), st)) {
+                for (int base = 0; base < 11; base += C::VW) { RR_FOR_LANES(l) { if (base + l < 11) o.obs_g()[base + l] = (O)NAN; } }
             }
         }
         if (RR_IS_LANE0) {
-            *o.reward = (O)0; *o.done = 1;
-            if (o.reward_g) *o.reward_g = (O)0;
-            if (o.status) *o.status = st;
+            *o.reward() = (O)0; *o.done() = 1;
+            if (o.reward_g()) *o.reward_g() = (O)0;
+            if (o.status()) *o.status() = st;
         }
         return;
     }
@@ -1974,11 +1986,11 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
         // An expensive sub-step: has the arena, or the island that made it expensive, stopped changing?  (The snapshot
         // costs a round trip to the arena's HBM record, so it is only taken when a whole-arena fixed point is possible --
         // no robot moved -- or when the sub-step exhausted the resolve loop.)
-        if (o.snap && f + 1 < RR_NUM_SUBSTEPS && ((C::NR > 1 && work >= 12) || (work >= 3 && robots_unmoved(A)))) {
+        if (o.snap() && f + 1 < RR_NUM_SUBSTEPS && ((C::NR > 1 && work >= 12) || (work >= 3 && robots_unmoved(A)))) {
             uint32_t chg_r, chg_re, chg_b;
             bool ax_diff;
             const bool have = snap_at == f - 1;
-            snapshot_compare_update(A, o.snap, o.isnap, have, chg_r, chg_re, chg_b, ax_diff);
+            snapshot_compare_update(A, o.snap(), o.isnap(), have, chg_r, chg_re, chg_b, ax_diff);
             RR_TRACE("E snapshot at %d: have %d chg_r %x edges %x chg_b %x hit r %x b %x moved %x/%x work %d\n", f, (int)have, chg_r, chg_re, chg_b, hit.r, hit.b, prev_moved, snap_moved, work);
             if (have) {
                 if (!(chg_r | chg_re | chg_b) && !ax_diff && snap_moved == prev_moved) {
@@ -2037,20 +2049,20 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     const bool faulted = sp.reset_on_fault && (st & ST_FATAL); // the reference raised (or hangs) inside this step
     const bool done = is_done<R>(step_now, sp) || faulted;
     if constexpr (C::NRH > 0 && C::NRG > 0) {
-        if (o.obs_g) observe_both<C, O>(A, sp, o.obs, o.obs_g, st);
-        else observe<C, O>(A, sp, 1, -1, -1, o.obs, st);
+        if (o.obs_g()) observe_both<C, O>(A, sp, o.obs(), o.obs_g(), st);
+        else observe<C, O>(A, sp, 1, -1, -1, o.obs(), st);
     } else {
-        observe<C, O>(A, sp, 1, -1, -1, o.obs, st);
-        if (o.obs_g) {
-            if (!observe<C, O>(A, sp, -1, -1, -1, o.obs_g, st)) {
-                for (int base = 0; base < 11; base += C::VW) { RR_FOR_LANES(l) { if (base + l < 11) o.obs_g[base + l] = (O)NAN; } }
+        observe<C, O>(A, sp, 1, -1, -1, o.obs(), st);
+        if (o.obs_g()) {
+            if (!observe<C, O>(A, sp, -1, -1, -1, o.obs_g(), st)) {
+                for (int base = 0; base < 11; base += C::VW) { RR_FOR_LANES(l) { if (base + l < 11) o.obs_g()[base + l] = (O)NAN; } }
             }
         }
     }
     if (RR_IS_LANE0) {
-        *o.reward = (O)rew_h; *o.done = done ? 1 : 0;
-        if (o.reward_g) *o.reward_g = (O)rew_g;
-        if (o.status) *o.status = st | (int)(naughty << 16); // bits 16..: robots NaughtyBots flagged this step
+        *o.reward() = (O)rew_h; *o.done() = done ? 1 : 0;
+        if (o.reward_g()) *o.reward_g() = (O)rew_g;
+        if (o.status()) *o.status() = st | (int)(naughty << 16); // bits 16..: robots NaughtyBots flagged this step
         // episode bookkeeping for logging (the caller sums `score` the same way, Training_DQN_pytorch.py:345-346)
         A.p.acc[0] += rew_h; A.p.acc[1] += rew_g; A.i.ep_len += 1;
         if (done) { A.p.acc[2] = A.p.acc[0]; A.p.acc[3] = A.p.acc[1]; A.i.last_len = A.i.ep_len; A.i.ep_count += 1; }

@@ -141,7 +141,7 @@ template <class CC> static int emu_step_t(Emu<CC> *e, const int32_t *actions, co
     RR xs[3 * CC::NR + 1];
     Rec<CC> q = { reinterpret_cast<const RR *>(&e->A.p) };
     if (e->custom_prog) extras_begin<CC>(q, xs);
-    StepOut<double> o = { obs, obs_g, reward, reward_g, done, &status, g_dbg_memo ? e->snap : nullptr, e->isnap };
+    StepOut<double> o = { obs, obs_g, reward, reward_g, done, &status, g_dbg_memo ? e->snap : nullptr, e->isnap, 0, 0, 0 };
     step_arena<CC, double>(e->A, e->sp, 0, actions, thrust, na, o);
     if (e->custom_prog && !(status & (ST_WAS_RESET | ST_STEP_AFTER_DONE)))
         extras_end<CC, double>(q, e->sp, xs, e->prog, (uint32_t)status >> 16, reward, reward_g, &status);
