@@ -26,7 +26,9 @@ class DeepQNetwork(nn.Module):
         self.fc1 = nn.Linear(input_dims, fc1_dims)
         self.fc2 = nn.Linear(fc1_dims, fc2_dims)
         self.fc3 = nn.Linear(fc2_dims, n_actions)
+        # (the fused single-kernel Adam step where the parameters live on the GPU: the learn() call is launch-bound)
         self.optimizer = torch.optim.Adam(self.parameters(), lr=lr)
+        self._lr = lr
         self.loss = nn.MSELoss()
 
     def forward(self, state):
@@ -51,6 +53,8 @@ class BatchedDQNAgent:
         self.gen.manual_seed(seed)
         torch.manual_seed(seed)
         self.Q_eval = DeepQNetwork(lr, input_dims, fc1_dims, fc2_dims, n_actions).to(self.device)
+        if self.device.type == "cuda":
+            self.Q_eval.optimizer = torch.optim.Adam(self.Q_eval.parameters(), lr=lr, fused=True)
         self.Q_target = copy.deepcopy(self.Q_eval)
         m, d = self.mem_size, self.device
         self.state_memory = torch.zeros(m, input_dims, dtype=torch.float32, device=d)
