@@ -123,12 +123,19 @@ int rr_set_poses(rr_env *env, const double *robots_xyr, const double *balls_xyv,
  * Default {1,2,3}.  n <= 8. */
 int rr_set_reward_program(rr_env *env, const int32_t *keeper_ids, int32_t n);
 /* Observers: kind 0 SingleBall_6wayLidar_v2 (11 values), 1 SingleBall_6wayLidar (11, RR_Observers.py:168-285),
- * 2 PosBall_BasicLidar (5, :116-166), 3 AllCoords (3*NR + 2*NB, :47-83).  obs [N, out_dim]; rows are NaN where the
- * reference returns None.  out_dim must equal the kind's size. */
+ * 2 PosBall_BasicLidar (5, :116-166), 3 AllCoords (3*NR + 2*NB, :47-83), 4 AllCoords_WithPrior (6*NR + 4*NB, :86-110:
+ * every robot x, y, rot + its rectDblPriorStep x, y, rot, every ball x, y + prior-step x, y; needs
+ * rr_track_prior_step).  obs [N, out_dim]; rows are NaN where the reference returns None.  out_dim must equal the
+ * kind's size. */
 int rr_observe_kind(rr_env *env, int32_t kind, int32_t team, int32_t robot_idx, int32_t ball_idx, float *obs,
                     int32_t out_dim, void *stream);
 int rr_observe_kind_f64(rr_env *env, int32_t kind, int32_t team, int32_t robot_idx, int32_t ball_idx, double *obs,
                         int32_t out_dim, void *stream);
+
+/* on != 0: every rr_step / rr_step_thrust first snapshots what the sprites' on_step_begin copies (rectDblPriorStep,
+ * RR_Robot.py:116-117, RR_Ball.py:60-61) so that observer kind 4 can report it; the call itself (and rr_reset) seeds the
+ * copies from the current poses (the reference holds the stale pre-placement pose until the first step). */
+int rr_track_prior_step(rr_env *env, int32_t on, void *stream);
 
 /* Logging: return/length of the last finished episode and the number of finished episodes per arena
  * (the caller accumulates `score` the same way, Training_DQN_pytorch.py:345-346). */

@@ -456,6 +456,7 @@ def alt_observations(R, env):
         out["v1_" + tag] = np.full(11, NAN) if v1 is None else np.asarray(v1, dtype=np.float64)
         out["basic_" + tag] = np.full(5, NAN) if bas is None else np.asarray(bas, dtype=np.float64)
         out["all_" + tag] = np.asarray(call(O.AllCoords, int_team=team), dtype=np.float64)
+        out["allp_" + tag] = np.asarray(call(O.AllCoords_WithPrior, int_team=team), dtype=np.float64)
     last = env.lstRobots[-1]
     out["basic_last"] = np.asarray(call(O.PosBall_BasicLidar, obj_robot=last), dtype=np.float64)
     out["v1_last_negball"] = np.asarray(call(O.SingleBall_6wayLidar, obj_robot=last, obj_ball=env.lstBalls[-1]), dtype=np.float64)
@@ -494,7 +495,7 @@ def gen_mix(R, preset):
             nsteps = 160 if preset == "G" else 260
             S = dict(robots=[], robots_i=[], balls=[], inner=[], step=[])
             rec = {k: [] for k in ("actions", "reward", "reward_g", "done", "v1_h", "v1_g", "basic_h", "basic_g", "all_h", "all_g",
-                                   "basic_last", "v1_last_negball")}
+                                   "allp_h", "allp_g", "basic_last", "v1_last_negball")}
 
             def put():
                 d = dump_state(env, R)

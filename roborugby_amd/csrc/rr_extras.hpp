@@ -12,7 +12,10 @@ namespace rr {
 
 enum : int { KEEPER_NAUGHTY = 1, KEEPER_CHASE = 2, KEEPER_PUSHPOS = 3, KEEPER_DONTDRIVE = 4, KEEPER_KEEPMOVING = 5,
              KEEPER_BASEDESTRUCTION = 6, KEEPER_PUSHNEG = 7 };
-enum : int { OBS_V2 = 0, OBS_V1 = 1, OBS_BASIC = 2, OBS_ALLCOORDS = 3 };
+enum : int { OBS_V2 = 0, OBS_V1 = 1, OBS_BASIC = 2, OBS_ALLCOORDS = 3, OBS_ALLCOORDS_PRIOR = 4 };
+// words of the on_step_begin snapshot per arena: rectDblPriorStep copies of the robots (cx, cy, rot), ball_dist_sum,
+// rectDblPriorStep copies of the balls (cx, cy)
+template <class C> constexpr int xs_stride() { return 3 * C::NR + 1 + 2 * C::NB; }
 
 struct Program { int32_t n; int32_t id[8]; };
 
@@ -45,7 +48,7 @@ template <typename R> RR_HD bool goal_contains(bool happy, R W, R H, V2<R> p, in
     return spn >= sh;
 }
 
-// ---- on_step_begin snapshot: [3*NR] rectDblPriorStep copies (cx, cy, rot) + ball_dist_sum
+// ---- on_step_begin snapshot: [3*NR] rectDblPriorStep copies (cx, cy, rot) + ball_dist_sum + [2*NB] ball copies
 template <class C> RR_HD void extras_begin(const Rec<C> &q, typename C::Real *xs) {
     using R = typename C::Real;
     for (int r = 0; r < C::NR; r++) { // FloatRect.copy(): new rect (0,20,0,40) -> center setter -> rotation setter
@@ -57,6 +60,10 @@ template <class C> RR_HD void extras_begin(const Rec<C> &q, typename C::Real *xs
     V2<R> o = { (R)0, (R)0 };
     for (int b = 0; b < C::NBP; b++) { V2<R> c = { q.bcx(b), q.bcy(b) }; s = s + dist<R>(o, c); }
     xs[3 * C::NR] = s;
+    for (int b = 0; b < C::NB; b++) { // Ball.on_step_begin (RR_Ball.py:60-61): FloatRect.copy() of a 14 x 14 rect
+        xs[3 * C::NR + 1 + 2 * b] = (R)7 + (q.bcx(b) - (R)7);
+        xs[3 * C::NR + 2 + 2 * b] = (R)7 + (q.bcy(b) - (R)7);
+    }
 }
 // ---- on_step_end: the keeper program in execution order
 template <class C, typename O>
@@ -138,9 +145,25 @@ RR_HD void lidar_serial(const Rec<C> &q, const SimParams<typename C::Real> &sp, 
 }
 // the other observers; returns the number of values written (0 = the reference returns None)
 template <class C, typename O>
-RR_HD int observe_kind(const Rec<C> &q, const SimParams<typename C::Real> &sp, int kind, int team, int ridx, int bidx, O *o) {
+RR_HD int observe_kind(const Rec<C> &q, const SimParams<typename C::Real> &sp, int kind, int team, int ridx, int bidx, O *o,
+                       const typename C::Real *xs = nullptr) {
     using R = typename C::Real;
     int st = 0;
+    if (kind == OBS_ALLCOORDS_PRIOR) { // AllCoords_WithPrior (RR_Observers.py:86-110); xs = the on_step_begin snapshot
+        if (!xs) return 0;
+        int n = 0;
+        const int f0 = team == -1 ? C::NRH : 0, f1 = team == -1 ? C::NR : C::NRH, s0 = team == -1 ? 0 : C::NRH, s1 = team == -1 ? C::NRH : C::NR;
+        for (int pass = 0; pass < 2; pass++)
+            for (int r = pass ? s0 : f0; r < (pass ? s1 : f1); r++) {
+                o[n++] = (O)q.rcx(r); o[n++] = (O)q.rcy(r); o[n++] = (O)q.rrot(r);
+                o[n++] = (O)xs[3 * r]; o[n++] = (O)xs[3 * r + 1]; o[n++] = (O)xs[3 * r + 2];
+            }
+        for (int b = 0; b < C::NB; b++) {
+            o[n++] = (O)q.bcx(b); o[n++] = (O)q.bcy(b);
+            o[n++] = (O)xs[3 * C::NR + 1 + 2 * b]; o[n++] = (O)xs[3 * C::NR + 2 + 2 * b];
+        }
+        return n;
+    }
     if (kind == OBS_ALLCOORDS) { // AllCoords (RR_Observers.py:47-83): own team's robots first
         int n = 0;
         const int f0 = team == -1 ? C::NRH : 0, f1 = team == -1 ? C::NR : C::NRH, s0 = team == -1 ? 0 : C::NRH, s1 = team == -1 ? C::NRH : C::NR;

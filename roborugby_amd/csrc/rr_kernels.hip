@@ -282,11 +282,11 @@ __global__ void k_episode_stats(const typename C::Real *recs, const int32_t *ire
 
 // ---- other mixins (rr_extras.hpp): thread-per-arena side kernels, straight from the HBM records
 template <class C>
-__global__ void k_extras_begin(const typename C::Real *recs, int n, typename C::Real *xs) {
+__global__ void k_extras_begin(const typename C::Real *recs, int n, typename C::Real *xs, const uint8_t *mask = nullptr) {
     int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= n) return;
+    if (a >= n || (mask && !mask[a])) return;
     Rec<C> q = { recs + (size_t)a * Arena<C>::P_STRIDE };
-    extras_begin<C>(q, xs + (size_t)a * (3 * C::NR + 1));
+    extras_begin<C>(q, xs + (size_t)a * xs_stride<C>());
 }
 template <class C, typename O>
 __global__ void k_extras_end(SimParams<typename C::Real> sp, const typename C::Real *recs, int n, const typename C::Real *xs,
@@ -296,17 +296,17 @@ __global__ void k_extras_end(SimParams<typename C::Real> sp, const typename C::R
     const int32_t st = status[a];
     if (st & (ST_WAS_RESET | ST_STEP_AFTER_DONE)) return; // nothing was stepped: the reward stays 0
     Rec<C> q = { recs + (size_t)a * Arena<C>::P_STRIDE };
-    extras_end<C, O>(q, sp, xs + (size_t)a * (3 * C::NR + 1), pg, (uint32_t)st >> 16, reward + a, reward_g ? reward_g + a : nullptr,
+    extras_end<C, O>(q, sp, xs + (size_t)a * xs_stride<C>(), pg, (uint32_t)st >> 16, reward + a, reward_g ? reward_g + a : nullptr,
                      status + a);
 }
 template <class C, typename O>
 __global__ void k_observe_kind(SimParams<typename C::Real> sp, const typename C::Real *recs, int n, int kind, int team, int ridx,
-                               int bidx, O *obs, int dim) {
+                               int bidx, O *obs, int dim, const typename C::Real *xs) {
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
     Rec<C> q = { recs + (size_t)a * Arena<C>::P_STRIDE };
-    O tmp[3 * C::NR + 2 * C::NB > 11 ? 3 * C::NR + 2 * C::NB : 11];
-    const int m = observe_kind<C, O>(q, sp, kind, team, ridx, bidx, tmp);
+    O tmp[6 * C::NR + 4 * C::NB > 11 ? 6 * C::NR + 4 * C::NB : 11];
+    const int m = observe_kind<C, O>(q, sp, kind, team, ridx, bidx, tmp, xs ? xs + (size_t)a * xs_stride<C>() : nullptr);
     for (int k = 0; k < dim; k++) obs[(size_t)a * dim + k] = k < m ? tmp[k] : (O)NAN;
 }
 
@@ -334,6 +334,7 @@ struct rr_env {
     SimParams<float> spf;
     Program prog;        // reward keepers in execution order
     bool custom_prog;    // != SimpleDuel3's {Naughty, Chase, PushPos}
+    bool track_prior;    // keep the on_step_begin snapshot up to date for AllCoords_WithPrior (rr_track_prior_step)
     void *xs;            // on_step_begin snapshot for the side kernels (lazy)
     int32_t *status_buf; // internal status when the caller passes none but the side kernels need it (lazy)
     uint32_t *order;     // slowest-first dispatch order of the arena groups (null: index order)
@@ -415,7 +416,7 @@ int rr_create(const rr_config *cfg, rr_env **out) {
     e->kind = shape + 2 * (cfg->dtype == RR_DTYPE_F32 ? 1 : 0);
     e->vw = 0;
     e->prog.n = 3; e->prog.id[0] = KEEPER_NAUGHTY; e->prog.id[1] = KEEPER_CHASE; e->prog.id[2] = KEEPER_PUSHPOS;
-    e->custom_prog = false; e->xs = nullptr; e->status_buf = nullptr;
+    e->custom_prog = false; e->track_prior = false; e->xs = nullptr; e->status_buf = nullptr;
     const char *want = getenv("RR_VW");
     const int want_vw = want ? atoi(want) : 0;
 #define X(kind_, a, b, c, d, R_, vw_) \
@@ -497,6 +498,8 @@ int rr_reset(rr_env *e, const uint8_t *mask, float *obs, float *obs_g, void *str
         using CC = decltype(c); using RR = typename CC::Real;
         hipLaunchKernelGGL((k_reset<CC, float>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
                            (RR *)e->recs, e->irecs, n, mask, 0, obs, obs_g);
+        if (e->track_prior && e->xs) // a re-placed arena has no prior step yet: its copies restart from the new poses
+            hipLaunchKernelGGL((k_extras_begin<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const RR *)e->recs, n, (RR *)e->xs, mask);
         return 0;
     });
     if (rc) return rc;
@@ -527,8 +530,8 @@ static int step_impl(rr_env *e, const int32_t *actions, const float *thrust, int
         if constexpr (std::is_same<O, double>::value && !std::is_same<RR, double>::value) {
             return fail(-1, "fp64 outputs need a handle created with RR_DTYPE_F64");
         } else {
-            if (e->custom_prog)
-                hipLaunchKernelGGL((k_extras_begin<CC>), dim3((n + 127) / 128), dim3(128), 0, s, (const RR *)e->recs, n, (RR *)e->xs);
+            if (e->custom_prog || e->track_prior)
+                hipLaunchKernelGGL((k_extras_begin<CC>), dim3((n + 127) / 128), dim3(128), 0, s, (const RR *)e->recs, n, (RR *)e->xs, (const uint8_t *)nullptr);
             hipLaunchKernelGGL((k_step<CC, O>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (RR *)e->recs, e->irecs, n,
                                actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status, (const uint32_t *)e->order, e->cost);
             if (e->order) hipLaunchKernelGGL(k_order, dim3(1), dim3(ORDER_THREADS), 0, s, (const uint32_t *)e->cost, e->order, e->ngroups);
@@ -560,6 +563,14 @@ int rr_step_f64(rr_env *e, const int32_t *actions, int32_t na, double *obs, doub
     return step_impl<double>(e, actions, nullptr, na, obs, reward, done, obs_g, reward_g, status, stream);
 }
 
+static int ensure_snapshot_buffer(rr_env *e) { // on_step_begin snapshot of every arena (xs_stride reals each)
+    if (e->xs) return 0;
+    const size_t rsz = e->cfg.dtype == RR_DTYPE_F32 ? 4 : 8;
+    const size_t nr = (size_t)(e->cfg.nr_happy + e->cfg.nr_grumpy), nb = (size_t)(e->cfg.nb_pos + e->cfg.nb_neg);
+    HIP_TRY(hipMalloc(&e->xs, rsz * (3 * nr + 1 + 2 * nb) * (size_t)e->cfg.num_envs));
+    return 0;
+}
+
 int rr_set_reward_program(rr_env *e, const int32_t *ids, int32_t n) {
     if (!e || (!ids && n > 0)) return fail(-1, "rr_set_reward_program: null argument");
     if (n < 0 || n > 8) return fail(-1, "rr_set_reward_program: at most 8 keepers");
@@ -569,12 +580,29 @@ int rr_set_reward_program(rr_env *e, const int32_t *ids, int32_t n) {
     e->prog.n = n;
     for (int i = 0; i < n; i++) e->prog.id[i] = ids[i];
     e->custom_prog = !(n == 3 && ids[0] == KEEPER_NAUGHTY && ids[1] == KEEPER_CHASE && ids[2] == KEEPER_PUSHPOS);
-    if (e->custom_prog && !e->xs) { // allocated here, never inside rr_step (keeps the step launch-only)
-        const size_t rsz = e->cfg.dtype == RR_DTYPE_F32 ? 4 : 8;
-        const size_t nr = (size_t)(e->cfg.nr_happy + e->cfg.nr_grumpy);
-        HIP_TRY(hipMalloc(&e->xs, rsz * (3 * nr + 1) * (size_t)e->cfg.num_envs));
-        HIP_TRY(hipMalloc((void **)&e->status_buf, sizeof(int32_t) * (size_t)e->cfg.num_envs));
+    if (e->custom_prog) { // allocated here, never inside rr_step (keeps the step launch-only)
+        if (int rc = ensure_snapshot_buffer(e)) return rc;
+        if (!e->status_buf) HIP_TRY(hipMalloc((void **)&e->status_buf, sizeof(int32_t) * (size_t)e->cfg.num_envs));
     }
+    return 0;
+}
+
+int rr_track_prior_step(rr_env *e, int32_t on, void *stream) {
+    if (!e) return fail(-1, "rr_track_prior_step: null handle");
+    DeviceGuard guard(e->cfg.device);
+    e->track_prior = on != 0;
+    if (!e->track_prior) return 0;
+    if (int rc = ensure_snapshot_buffer(e)) return rc;
+    // until the first step the prior-step copies are copies of the current state (the reference's hold the stale
+    // pre-placement pose there: Robot.on_reset / Ball.on_reset copy BEFORE _set_random_positions moves the sprites)
+    const int n = e->cfg.num_envs;
+    int rc = dispatch(e, [&](auto c) {
+        using CC = decltype(c); using RR = typename CC::Real;
+        hipLaunchKernelGGL((k_extras_begin<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const RR *)e->recs, n, (RR *)e->xs, (const uint8_t *)nullptr);
+        return 0;
+    });
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -584,9 +612,12 @@ static int observe_kind_impl(rr_env *e, int32_t kind, int32_t team, int32_t ridx
     if (!e || !obs) return fail(-1, "rr_observe_kind: null argument");
     const int nr = e->cfg.nr_happy + e->cfg.nr_grumpy, nb = e->cfg.nb_pos + e->cfg.nb_neg;
     if ((team != 1 && team != -1) || ridx >= nr || bidx >= nb) return fail(-1, "rr_observe_kind: bad team/robot/ball index");
-    const int want = kind == OBS_V2 || kind == OBS_V1 ? 11 : kind == OBS_BASIC ? 5 : kind == OBS_ALLCOORDS ? 3 * nr + 2 * nb : -1;
+    const int want = kind == OBS_V2 || kind == OBS_V1 ? 11 : kind == OBS_BASIC ? 5 : kind == OBS_ALLCOORDS ? 3 * nr + 2 * nb :
+                     kind == OBS_ALLCOORDS_PRIOR ? 6 * nr + 4 * nb : -1;
     if (want < 0) return fail(-1, "rr_observe_kind: unknown observer kind");
     if (out_dim != want) return fail(-1, "rr_observe_kind: out_dim does not match the observer's size");
+    if (kind == OBS_ALLCOORDS_PRIOR && !(e->track_prior && e->xs))
+        return fail(-1, "rr_observe_kind: AllCoords_WithPrior needs rr_track_prior_step(env, 1) before the step it looks back on");
     const int n = e->cfg.num_envs;
     DeviceGuard guard(e->cfg.device);
     int rc = dispatch(e, [&](auto c) {
@@ -599,7 +630,8 @@ static int observe_kind_impl(rr_env *e, int32_t kind, int32_t team, int32_t ridx
                                    (const RR *)e->recs, (const int32_t *)e->irecs, n, (int)team, (int)ridx, (int)bidx, obs);
             else
                 hipLaunchKernelGGL((k_observe_kind<CC, O>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, params_of<RR>(e),
-                                   (const RR *)e->recs, n, (int)kind, (int)team, (int)ridx, (int)bidx, obs, (int)out_dim);
+                                   (const RR *)e->recs, n, (int)kind, (int)team, (int)ridx, (int)bidx, obs, (int)out_dim,
+                                   kind == OBS_ALLCOORDS_PRIOR ? (const RR *)e->xs : (const RR *)nullptr);
             return 0;
         }
     });

@@ -34,7 +34,12 @@ STATUS_FLAG_MASK, STATUS_NAUGHTY_SHIFT = 0xFFFF, 16  # info.status: flags in bit
 # reward mixins of RR_ScoreKeepers.py (ids of the C-ABI's keeper program) and observer mixins of RR_Observers.py
 KEEPERS = {"NaughtyBots": 1, "ChasePosBall": 2, "PushPosBallsToGoal": 3, "DontDriveInGoals": 4, "KeepMovingGuys": 5,
            "BaseDestruction": 6, "PushNegBallsFromGoal": 7}
-OBSERVERS = {"SingleBall_6wayLidar_v2": 0, "SingleBall_6wayLidar": 1, "PosBall_BasicLidar": 2, "AllCoords": 3}
+OBSERVERS = {"SingleBall_6wayLidar_v2": 0, "SingleBall_6wayLidar": 1, "PosBall_BasicLidar": 2, "AllCoords": 3,
+             "AllCoords_WithPrior": 4}
+
+
+def observer_dim(kind, nr, nb):
+    return {0: 11, 1: 11, 2: 5, 3: 3 * nr + 2 * nb, 4: 6 * nr + 4 * nb}[kind]
 SIMPLE_DUEL3_REWARDS = ("PushPosBallsToGoal", "ChasePosBall", "NaughtyBots")  # RR_Environments.py:27-32
 
 
@@ -121,7 +126,9 @@ class BatchedRoboRugbyEnv:
         if observer not in OBSERVERS:
             raise KeyError(f"unknown observer {observer!r}; available: {sorted(OBSERVERS)}")
         self.observer, self.obs_kind = observer, OBSERVERS[observer]
-        self.obs_dim = {0: 11, 1: 11, 2: 5, 3: 3 * p.nr + 2 * p.nb}[self.obs_kind]
+        self.obs_dim = observer_dim(self.obs_kind, p.nr, p.nb)
+        if self.obs_kind == 4:  # the prior-step copies have to be snapshotted at every on_step_begin from now on
+            _lib.check(self._lib.rr_track_prior_step(self._h, 1, self._stream()), "rr_track_prior_step")
         self.rewards = tuple(rewards)
         prog = np.asarray(keeper_exec_order(self.rewards), np.int32)
         _lib.check(self._lib.rr_set_reward_program(self._h, prog.ctypes.data_as(C.c_void_p), len(prog)),
@@ -224,9 +231,9 @@ class BatchedRoboRugbyEnv:
         returns None (the team has no robot)."""
         team = 1 if int_team is None else int(int_team)
         kind = self.obs_kind if observer is None else OBSERVERS[observer]
-        if kind != 3 and robot_idx < 0 and ((team == 1 and self.preset.nr_happy == 0) or (team == -1 and self.preset.nr_grumpy == 0)):
+        if kind not in (3, 4) and robot_idx < 0 and ((team == 1 and self.preset.nr_happy == 0) or (team == -1 and self.preset.nr_grumpy == 0)):
             return None
-        dim = {0: 11, 1: 11, 2: 5, 3: 3 * self.preset.nr + 2 * self.preset.nb}[kind]
+        dim = observer_dim(kind, self.preset.nr, self.preset.nb)
         obs = self._new((self.num_envs, dim), torch.float64 if f64 else torch.float32)
         fn = self._lib.rr_observe_kind_f64 if f64 else self._lib.rr_observe_kind
         _lib.check(fn(self._h, kind, team, int(robot_idx), int(ball_idx), _ptr(obs), dim, self._stream()), "rr_observe_kind")

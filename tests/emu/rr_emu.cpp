@@ -21,6 +21,7 @@ template <class C> struct Emu {
     Program prog;     // reward keepers in execution order (default = SimpleDuel3)
     bool custom_prog;
     uint32_t snap[Arena<C>::P_STRIDE * sizeof(typename C::Real) / 4];
+    typename C::Real xs[3 * C::NR + 1 + 2 * C::NB]; // on_step_begin snapshot (always taken here: AllCoords_WithPrior reads it)
     int32_t isnap[C::NR];
 };
 
@@ -138,9 +139,9 @@ template <class CC> static int emu_step_t(Emu<CC> *e, const int32_t *actions, co
                                           double *obs_g, double *reward, double *reward_g, uint8_t *done) {
     using RR = typename CC::Real;
     int32_t status = 0;
-    RR xs[3 * CC::NR + 1];
+    RR *xs = e->xs;
     Rec<CC> q = { reinterpret_cast<const RR *>(&e->A.p) };
-    if (e->custom_prog) extras_begin<CC>(q, xs);
+    extras_begin<CC>(q, xs);
     StepOut<double> o = { obs, obs_g, reward, reward_g, done, &status, g_dbg_memo ? e->snap : nullptr, e->isnap, 0, 0, 0 };
     step_arena<CC, double>(e->A, e->sp, 0, actions, thrust, na, o);
     if (e->custom_prog && !(status & (ST_WAS_RESET | ST_STEP_AFTER_DONE)))
@@ -168,7 +169,7 @@ int emu_observe_kind(Handle *h, int kind, int team, int ridx, int bidx, double *
     int m = 0;
     DISPATCH(h, if (kind == 0) { int st = 0; m = observe<CC, double>(e->A, e->sp, team, ridx, bidx, out, st) ? 11 : 0; }
                 else { Rec<CC> q = { reinterpret_cast<const typename CC::Real *>(&e->A.p) };
-                       m = observe_kind<CC, double>(q, e->sp, kind, team, ridx, bidx, out); });
+                       m = observe_kind<CC, double>(q, e->sp, kind, team, ridx, bidx, out, e->xs); });
     return m;
 }
 int emu_observe(Handle *h, int team, int ridx, int bidx, double *obs) {

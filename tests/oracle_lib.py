@@ -123,7 +123,8 @@ class OracleEnv:
         lib().rro_set_program(self.h, _ip(a), len(a))
 
     def observe_kind(self, kind, team=1, robot=-1, ball=-1):
-        """kind 0 = SingleBall_6wayLidar_v2, 1 = SingleBall_6wayLidar, 2 = PosBall_BasicLidar, 3 = AllCoords."""
+        """kind 0 = SingleBall_6wayLidar_v2, 1 = SingleBall_6wayLidar, 2 = PosBall_BasicLidar, 3 = AllCoords,
+        4 = AllCoords_WithPrior."""
         o = np.zeros(64)
         n = lib().rro_observe_kind(self.h, kind, team, robot, ball, _dp(o))
         return o[:n].copy() if n > 0 else None

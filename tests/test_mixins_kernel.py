@@ -33,6 +33,7 @@ def test_emulated_side_kernels_vs_reference_golden(golden_dir, preset):
             assert abs(r["reward"] - t["reward"][ep, s]) < 1e-7 and abs(r["reward_g"] - t["reward_g"][ep, s]) < 1e-7, (preset, ep, s)
             assert _close(env.observe_kind(1, 1), t["v1_h"][ep, s]) and _close(env.observe_kind(2, 1), t["basic_h"][ep, s])
             assert _close(env.observe_kind(3, 1), t["all_h"][ep, s]) and _close(env.observe_kind(3, -1), t["all_g"][ep, s])
+            assert _close(env.observe_kind(4, 1), t["allp_h"][ep, s]) and _close(env.observe_kind(4, -1), t["allp_g"][ep, s])
             if has_g:
                 assert _close(env.observe_kind(1, -1), t["v1_g"][ep, s]) and _close(env.observe_kind(2, -1), t["basic_g"][ep, s])
             else:
@@ -76,6 +77,17 @@ def test_gpu_mixin_stacks_vs_reference_golden(golden_dir, preset):
                                 ("AllCoords", "all", -1)):
             got = env.get_game_state(team, f64=True, observer=name).cpu().numpy()
             assert _close(got, t[f"{key}_{'h' if team == 1 else 'g'}"][ep, st]), (preset, which, name, team)
+        # AllCoords_WithPrior needs the on_step_begin snapshot: an env configured with that observer tracks it
+        envp = rr.BatchedRoboRugbyEnv(len(idx), preset=preset, time_limit=False, auto_reset=False, rewards=tuple(stack),
+                                      observer="AllCoords_WithPrior")
+        assert envp.observation_space.shape == (6 * nr + 4 * rr.PRESETS[preset].nb,)
+        envp.set_state(t["state_robots"][ep, st], t["state_robots_i"][ep, st], t["state_balls"][ep, st], t["state_step"][ep, st])
+        envp.step_f64(torch.as_tensor(t["actions"][ep, st].astype(np.int32)))
+        for team in (1, -1):
+            got = envp.get_game_state(team, f64=True).cpu().numpy()
+            assert _close(got, t[f"allp_{'h' if team == 1 else 'g'}"][ep, st]), (preset, which, "AllCoords_WithPrior", team)
+        with pytest.raises(RuntimeError):
+            env.get_game_state(1, observer="AllCoords_WithPrior")  # this env never asked for the snapshot
         if preset == "G":
             got = env.get_game_state(-1, f64=True, observer="SingleBall_6wayLidar").cpu().numpy()
             assert _close(got, t["v1_g"][ep, st])

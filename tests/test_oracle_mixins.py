@@ -3,7 +3,7 @@ against tests/golden/mix_*.npz: episodes of two mixin stacks the reference can c
   MixA = DontDriveInGoals, KeepMovingGuys, PushNegBallsFromGoal, BaseDestruction, PushPosBallsToGoal, ChasePosBall
   MixB = KeepMovingGuys, NaughtyBots, DontDriveInGoals   (NaughtyBots.on_step_end never calls super(): the keepers
          behind it in the MRO do not run -- RR_ScoreKeepers.py:130-135)
-plus the SingleBall_6wayLidar / PosBall_BasicLidar / AllCoords observations of the same states."""
+plus the SingleBall_6wayLidar / PosBall_BasicLidar / AllCoords / AllCoords_WithPrior observations of the same states."""
 import json
 
 import numpy as np
@@ -41,6 +41,7 @@ def test_mixin_rewards_and_observers_bit_exact(golden_dir, preset):
             assert _eq(env.observe_kind(2, 1), t["basic_h"][ep, s])
             assert _eq(env.observe_kind(3, 1), t["all_h"][ep, s])
             assert _eq(env.observe_kind(3, -1), t["all_g"][ep, s])
+            assert _eq(env.observe_kind(4, 1), t["allp_h"][ep, s]) and _eq(env.observe_kind(4, -1), t["allp_g"][ep, s])  # AllCoords_WithPrior
             if has_g:
                 assert _eq(env.observe_kind(1, -1), t["v1_g"][ep, s])
                 assert _eq(env.observe_kind(2, -1), t["basic_g"][ep, s])
