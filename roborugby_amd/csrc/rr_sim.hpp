@@ -336,6 +336,7 @@ template <class C> struct ArenaBody {
     int32_t bmass[NB];
     int32_t bbm[NB], brc[NB]; // per-ball hit / close bit masks of the contact sweeps (one lane per ball writes its own)
     R exc[NB];                // how far (L1) the contact responses of this sub-step have carried the ball from its frame-begin centre
+    R reach[NB];              // 14.04 + the most the ball can travel in this sub-step's roll: the ball-ball bound of the fused roll phase
     int32_t sides_ok; // sm/sc match the current robot poses (rebuilt lazily by the first phase that needs them)
     union { // the lidar candidates are only alive inside observe(), the inner-square offsets only inside a sub-step
         R irel[NR][9];                    // corner offsets of the ball's inner square at rot+45 (diameter end points)
@@ -810,6 +811,13 @@ template <class C> RR_HD void ball_exc_update(Arena<C> &A, int b) {
     const R e = m_abs(A.p.bcx[b] - A.pfx[b]) + m_abs(A.p.bcy[b] - A.pfy[b]);
     if (e > A.exc[b]) A.exc[b] = e;
 }
+// ball-ball bound of the fused roll phase: the other ball may be seen before or after its own roll, and a roll moves it by
+// at most |v| + |force| per axis (RR_Ball.py:78-105); +1 % and 0.02 px of slack.  Written at the frame hooks (force = 0) and
+// again by whoever changes a ball's velocity or force before the roll (the push).
+template <class C> RR_HD typename C::Real ball_reach(const Arena<C> &A, int b) {
+    using R = typename C::Real;
+    return (R)14.04 + ((m_abs(A.p.bvx[b]) + m_abs(A.bfx[b]) + m_abs(A.p.bvy[b]) + m_abs(A.bfy[b])) * (R)1.01 + (R)0.02);
+}
 struct Hit { uint32_t r, b; }; // robots / balls that took part in a hit (response, undo) during the sub-step
 
 // ------------------------------------------------------------------------------------------------ contact responses (wave-uniform, list order)
@@ -1263,6 +1271,7 @@ RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, co
             if (!(FZ && ((fz.b >> l) & 1u))) { // on_frame_begin (RR_Ball.py:63-68)
                 A.bmass[l] = 1; A.bfx[l] = (R)0; A.bfy[l] = (R)0; A.exc[l] = (R)0;
                 A.pfx[l] = ball_copy_c<R>(A.p.bcx[l]); A.pfy[l] = ball_copy_c<R>(A.p.bcy[l]);
+                A.reach[l] = (R)14.04 + ((m_abs(A.p.bvx[l]) + m_abs(A.p.bvy[l])) * (R)1.01 + (R)0.02);
                 for (int r2 = 0; r2 < C::NR; r2++) { // ball-robot: 22.36 + 9.9 (+ 3 px of robot motion)
                     R dx = A.p.bcx[l] - A.p.rcx[r2], dy = A.p.bcy[l] - A.p.rcy[r2];
                     c_br = c_br | (dx * dx + dy * dy <= (R)(36.0 * 36.0));
@@ -1315,9 +1324,8 @@ RR_HD void substep_phase2(Arena<C> &A, const SimParams<typename C::Real> &sp, co
             const R mx = A.p.bcx[l], my = A.p.bcy[l];
             for (int j = 0; j < C::NB; j++) {
                 R dx = A.p.bcx[j] - mx, dy = A.p.bcy[j] - my;
-                R tr = (m_abs(A.p.bvx[j]) + m_abs(A.bfx[j]) + m_abs(A.p.bvy[j]) + m_abs(A.bfy[j])) * (R)1.01 + (R)0.02;
-                if (FZ) tr = ((fz.b >> j) & 1u) ? A.exc[j] + (R)0.02 : tr; // a frozen ball: wherever its island carried it
-                R reach = (R)14.04 + tr;
+                R reach = A.reach[j];
+                if (FZ) reach = ((fz.b >> j) & 1u) ? (R)14.06 + A.exc[j] : reach; // a frozen ball: wherever its island carried it
                 c = c | ((j != l) & (dx * dx + dy * dy <= reach * reach));
             }
             for (int r = 0; r < C::NR; r++) {
@@ -1343,6 +1351,10 @@ RR_HD void push_balls(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32
         apply_force_to_ball(A, sp, p % C::NR, p / C::NR, bots_moved, st);
         bounce_ball_off_bot(A, sp, p % C::NR, p / C::NR, bots_moved, st);
     }
+    if (br) { // the pushed balls' force and velocity changed: their roll bound with them
+        RR_FOR_LANES(l) { if (l < C::NB) A.reach[l] = ball_reach(A, l); }
+        RR_SYNC();
+    }
 }
 // the frozen island catches up with phase 1: frame hooks of its robots and balls, and the robots' moves
 template <class C> RR_HD void thaw_island(Arena<C> &A, const SimParams<typename C::Real> &sp, Hit &fz, uint32_t &bots_moved) {
@@ -1355,6 +1367,7 @@ template <class C> RR_HD void thaw_island(Arena<C> &A, const SimParams<typename 
         if (l < C::NB && ((fz.b >> l) & 1u)) {
             A.bmass[l] = 1; A.bfx[l] = (R)0; A.bfy[l] = (R)0; A.exc[l] = (R)0;
             A.pfx[l] = ball_copy_c<R>(A.p.bcx[l]); A.pfy[l] = ball_copy_c<R>(A.p.bcy[l]);
+            A.reach[l] = (R)14.04 + ((m_abs(A.p.bvx[l]) + m_abs(A.p.bvy[l])) * (R)1.01 + (R)0.02);
         }
     }
     RR_SYNC();
@@ -1416,9 +1429,8 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     }
     RR_STAMP(3);
     // phase 2: _roll_balls AND the fused first pass of _resolve_ball_collisions: anything possibly touching?  Ball-ball
-    // runs in the same phase as the roll, so the other ball may be seen before or after its own roll: the bound adds
-    // the most it can still travel (|v| + |force| per axis, +1 % and the 0.005 dead band for a velocity read after its
-    // damping).  Ball-robot uses the settled robot centres; the wall test is the exact int-rect test.
+    // runs in the same phase as the roll, so the other ball may be seen before or after its own roll: the bound (A.reach,
+    // written at the frame hooks and refreshed by the push) adds the most it can travel in its roll.  Ball-robot uses the settled robot centres; the wall test is the exact int-rect test.
     uint64_t m_any = 0;
     if (frozen && (fz.r | fz.b)) substep_phase2<C, true>(A, sp, fz, m_any);
     else substep_phase2<C, false>(A, sp, fz, m_any);
