@@ -813,9 +813,11 @@ template <class C> RR_HD uint64_t detect_ball_pairs(Arena<C> &A) {
 }
 // collided_wall on the int-truncated rect (RR_TrashyPhysics.py:76-85, RR_Ball.py:8-15)
 template <class C> RR_HD bool ball_collided_wall(const Arena<C> &A, const SimParams<typename C::Real> &sp, int b) {
-    long L = (long)A.p.bl[b], T = (long)A.p.bt[b];
-    long Wd = (long)(A.p.brt[b] - A.p.bl[b]), Ht = (long)(A.p.bb[b] - A.p.bt[b]);
-    return L < 0 || L + Wd > (long)sp.W || T < 0 || T + Ht > (long)sp.H;
+    // pygame.Rect holds C ints: truncation toward zero, which is what a float -> int32 conversion does (one instruction; a
+    // 64-bit conversion is a dozen).  Ball coordinates stay within a few arena widths of the arena, far inside int32.
+    const int L = (int)A.p.bl[b], T = (int)A.p.bt[b];
+    const int Wd = (int)(A.p.brt[b] - A.p.bl[b]), Ht = (int)(A.p.bb[b] - A.p.bt[b]);
+    return L < 0 || L + Wd > (int)sp.W || T < 0 || T + Ht > (int)sp.H;
 }
 template <class C> RR_HD uint32_t detect_ball_wall(const Arena<C> &A, const SimParams<typename C::Real> &sp) {
     uint64_t m = 0;
