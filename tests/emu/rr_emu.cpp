@@ -97,6 +97,9 @@ extern "C" {
 void emu_debug_set_substeps(int k) { g_dbg_substeps = k; }
 void emu_debug_trace(int on) { g_dbg_trace = on; }
 void emu_debug_memo(int on) { g_dbg_memo = on; }
+// primitives of the kernel source, for unit tests
+double emu_py_mod360(double a) { return py_mod<double>(a, 360.0); }
+void emu_sincos(double x, double *s, double *c) { m_sincos(x, *s, *c); }
 // preset: 0 = T, 1 = G ; f32: 0/1 ; f32 == 2 selects the narrow-virtual-wave fp64 build
 Handle *emu_create(int preset, int f32, double W, double H, int game_len, int game_mode, int time_limit, int auto_reset,
                    uint64_t seed) {

@@ -41,6 +41,9 @@ def lib():
         L.emu_reset.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
         L.emu_set_program.argtypes = [C.c_void_p, ip, C.c_int]
         L.emu_observe_kind.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+        L.emu_py_mod360.restype = C.c_double
+        L.emu_py_mod360.argtypes = [C.c_double]
+        L.emu_sincos.argtypes = [C.c_double, dp, dp]
         _lib = L
     return _lib
 
