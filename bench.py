@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--policy", default="random", choices=["random", "chase"])
     ap.add_argument("--log-interval", type=int, default=25, help="steps between RCCL all-gathers of episode returns")
+    ap.add_argument("--fuse", type=int, default=1, help="steps per launch (rr_rollout, open-loop extension; 1 = one launch per "
+                    "step like the reference's gym API -- the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -128,17 +130,29 @@ def main():
                 if na > 1 else a1
         return env.step(a, out=out)
 
-    for i in range(W):
-        one_step(i)
+    F = max(1, args.fuse)
+    if F > 1:
+        assert args.policy == "random" and K % F == 0 and W % F == 0, "--fuse needs the random policy and K, W multiples of it"
+        fout = (torch.empty(F, n, 11, device=dev), torch.empty(F, n, device=dev), torch.empty(F, n, dtype=torch.uint8, device=dev),
+                torch.empty(F, n, 11, device=dev) if p.nr_grumpy else None, torch.empty(F, n, device=dev),
+                torch.empty(F, n, dtype=torch.int32, device=dev))
+    for i in range(0, W, F):
+        if F > 1:
+            env.rollout(acts[i:i + F], out=fout)
+        else:
+            one_step(i)
     _, _, _, cnt0 = env.episode_stats()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     pending = []
     rrd.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(K):
+    resets_seen = 0
+    for i in range(0, K, F):
         ev[i][0].record()
-        if args.policy == "random":
+        if F > 1:
+            env.rollout(acts[W + i:W + i + F], out=fout)  # F steps per launch
+        elif args.policy == "random":
             env.step(acts[W + i], out=out)  # k_step (+ the few-microsecond k_order that sorts the next dispatch) between the two events
         else:
             one_step(W + i)
@@ -155,16 +169,17 @@ def main():
     dt = rrd.reduce_max(dt, dev)
     # steps that only re-placed a finished arena are not counted as env steps
     _, _, _, cnt1 = env.episode_stats()
-    resets = int((cnt1 - cnt0).sum().item()) - int(out[2].sum().item())
+    last_done = fout[2][-1] if F > 1 else out[2]  # arenas that finished in the very last step are re-placed by a later call
+    resets = int((cnt1 - cnt0).sum().item()) - int(last_done.sum().item())
     local_steps = n * K - max(resets, 0)
     total_steps = rrd.reduce_sum(float(local_steps), dev)
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / K
+    kern_ms = sum(ev[i][0].elapsed_time(ev[i][1]) for i in range(0, K, F)) / (K // F)  # per launch
     kern_ms = rrd.reduce_max(kern_ms, dev)
-    status_bits = int(torch.bitwise_and(out[5], 0xFFFF & ~1024 & ~256).max().item())
+    status_bits = int(torch.bitwise_and((fout if F > 1 else out)[5], 0xFFFF & ~1024 & ~256).max().item())
 
     if rank == 0:
         bytes_per_step = p.algorithmic_bytes_per_step(na)            # G 601 B, T 149 B
-        achieved = bytes_per_step * n / (kern_ms * 1e-3) / 1e9         # GB/s, one launch = n arena-steps
+        achieved = bytes_per_step * n * F / (kern_ms * 1e-3) / 1e9     # GB/s, one launch = n * F arena-steps
         traffic = None
         tfile = os.path.join(REPO, "profiles", "traffic.json")          # PMC-derived HBM bytes per launch, if measured
         if os.path.exists(tfile):
@@ -183,7 +198,7 @@ def main():
                        "arenas_per_gpu": n, "preset": args.preset, "policy": args.policy, "lanes_per_arena": env.lanes_per_env(),
                        "sharding": f"dp{world} (independent arena shards, returns all-gathered every "
                                    f"{args.log_interval} steps)" if world > 1 else "single GPU",
-                       "fault_status_bits_seen": status_bits},
+                       "steps_per_launch": F, "fault_status_bits_seen": status_bits},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_step", "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": bytes_per_step,

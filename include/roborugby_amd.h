@@ -92,6 +92,16 @@ int rr_step(rr_env *env, const int32_t *actions, int32_t na, float *obs, float *
 /* Same step with fp64 outputs (full-precision parity checks). */
 int rr_step_f64(rr_env *env, const int32_t *actions, int32_t na, double *obs, double *reward, uint8_t *done,
                 double *obs_g, double *reward_g, int32_t *status, void *stream);
+/* Open-loop rollout: nsteps consecutive rr_step calls per arena in ONE launch -- the record stays in LDS, and no arena
+ * waits for the slowest arena of the batch between steps (a launch per step ends when its slowest wavefront does).
+ * actions [nsteps, N, na] (repeat == 0) or [N, na] applied at every step (repeat != 0: the action-repeat / frame-skip
+ * wrapper of RL practice); outputs are stacked per step: obs [nsteps, N, 11], reward / done / status [nsteps, N]
+ * (obs_g, reward_g, status nullable).  Bit-identical to calling rr_step nsteps times (auto-reset included).  The reference
+ * has no counterpart (gym steps one call at a time); policies that need step s's observation to choose step s+1's
+ * action use rr_step. */
+int rr_rollout(rr_env *env, const int32_t *actions, int32_t na, int32_t nsteps, int32_t repeat, float *obs, float *reward,
+               uint8_t *done, float *obs_g, float *reward_g, int32_t *status, void *stream);
+
 /* Continuous entry, GameEnv.step (RR_EnvBase.py:260-273): thrust [N,2*nk] float32 (L,R per robot),
  * rounded half-to-even like Python's round() (RR_Robot.py:100-102). */
 int rr_step_thrust(rr_env *env, const float *thrust, int32_t nk, float *obs, float *reward, uint8_t *done,

@@ -37,6 +37,7 @@ SYMBOLS = {
     "rr_step": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rr_step_f64": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rr_step_thrust": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rr_rollout": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rr_observe": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
     "rr_observe_f64": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
     "rr_set_reward_program": (C.c_int, [_vp, _vp, C.c_int32]),

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
                                                               int32_t *irecs, int n, const int32_t *actions,
                                                               const float *thrust, int na, O *obs, O *reward,
                                                               uint8_t *done, O *obs_g, O *reward_g, int32_t *status,
-                                                              const uint32_t *order, uint32_t *cost) {
+                                                              const uint32_t *order, uint32_t *cost, int nsteps, int repeat) {
     __shared__ Arena<C> lds[arenas_per_block<C>()];
     const int wave = threadIdx.x / C::VW; // virtual wave = arena slot in this workgroup
     // slowest-first dispatch: workgroup b steps the group of arenas that was the b-th slowest in the previous step
@@ -86,10 +86,18 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
     load_record(A, rec, irec);
     derive(A, sp);
     RR_STAMP(12);
-    StepOut<O> o = { obs, obs_g, reward, reward_g, done, status, sp.memo ? reinterpret_cast<uint32_t *>(recs) : nullptr, irecs, arena,
-                     (int)(Arena<C>::P_STRIDE * sizeof(typename C::Real) / 4), (int)Arena<C>::I_STRIDE };
-    step_arena<C, O>(A, sp, sp.arena_offset + (uint64_t)arena, actions ? actions + (size_t)arena * na : nullptr,
-                     thrust ? thrust + (size_t)arena * 2 * na : nullptr, na, o);
+    // nsteps consecutive GameEnv.step calls on the record held in LDS (rr_rollout; rr_step is nsteps = 1): step s reads its
+    // actions at [s][arena] (or the same ones again when `repeat`) and writes its outputs at [s][arena]
+#pragma unroll 1
+    for (int s = 0; s < nsteps; s++) {
+        const size_t so = (size_t)s * (size_t)n;
+        StepOut<O> o = { obs + so * 11, obs_g ? obs_g + so * 11 : nullptr, reward + so, reward_g ? reward_g + so : nullptr, done + so,
+                         status ? status + so : nullptr, sp.memo ? reinterpret_cast<uint32_t *>(recs) : nullptr, irecs, arena,
+                         (int)(Arena<C>::P_STRIDE * sizeof(typename C::Real) / 4), (int)Arena<C>::I_STRIDE };
+        const size_t ao = repeat ? 0 : so;
+        step_arena<C, O>(A, sp, sp.arena_offset + (uint64_t)arena, actions ? actions + (ao + (size_t)arena) * na : nullptr,
+                         thrust ? thrust + (ao + (size_t)arena) * 2 * na : nullptr, na, o);
+    }
     RR_TR();
     {   // the record addresses again, from an arena index the optimiser cannot tie to the first one: otherwise the two
         // 64-bit pointers stay live across the whole step (4 VGPRs of a kernel that sits at the 256-VGPR limit)
@@ -99,7 +107,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
     }
     RR_STAMP(13);
     if (cost && threadIdx.x == 0) { // what this group cost, in shader clocks / 256 (saturating): next step's dispatch key
-        const unsigned long long dt = (__builtin_amdgcn_s_memtime() - t_begin) >> 8;
+        const unsigned long long dt = ((__builtin_amdgcn_s_memtime() - t_begin) >> 8) / (unsigned)nsteps; // per step
         cost[group] = dt > 0xFFFFull ? 0xFFFFu : (uint32_t)dt;
     }
 #if defined(RR_PROFILE_PHASES)
@@ -520,7 +528,7 @@ static int check_step_args(rr_env *e, const void *act, int32_t na, const void *o
 extern "C++" {
 template <typename O>
 static int step_impl(rr_env *e, const int32_t *actions, const float *thrust, int32_t na, O *obs, O *reward, uint8_t *done,
-                     O *obs_g, O *reward_g, int32_t *status, void *stream) {
+                     O *obs_g, O *reward_g, int32_t *status, void *stream, int nsteps = 1, int repeat = 0) {
     const int n = e->cfg.num_envs;
     DeviceGuard guard(e->cfg.device);
     hipStream_t s = (hipStream_t)stream;
@@ -533,7 +541,8 @@ static int step_impl(rr_env *e, const int32_t *actions, const float *thrust, int
             if (e->custom_prog || e->track_prior)
                 hipLaunchKernelGGL((k_extras_begin<CC>), dim3((n + 127) / 128), dim3(128), 0, s, (const RR *)e->recs, n, (RR *)e->xs, (const uint8_t *)nullptr);
             hipLaunchKernelGGL((k_step<CC, O>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (RR *)e->recs, e->irecs, n,
-                               actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status, (const uint32_t *)e->order, e->cost);
+                               actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status, (const uint32_t *)e->order, e->cost,
+                               nsteps, repeat);
             if (e->order) hipLaunchKernelGGL(k_order, dim3(1), dim3(ORDER_THREADS), 0, s, (const uint32_t *)e->cost, e->order, e->ngroups);
             if (e->custom_prog)
                 hipLaunchKernelGGL((k_extras_end<CC, O>), dim3((n + 127) / 128), dim3(128), 0, s, params_of<RR>(e),
@@ -551,6 +560,14 @@ int rr_step(rr_env *e, const int32_t *actions, int32_t na, float *obs, float *re
             float *reward_g, int32_t *status, void *stream) {
     if (int rc = check_step_args(e, actions, na, obs, reward, done)) return rc;
     return step_impl<float>(e, actions, nullptr, na, obs, reward, done, obs_g, reward_g, status, stream);
+}
+int rr_rollout(rr_env *e, const int32_t *actions, int32_t na, int32_t nsteps, int32_t repeat, float *obs, float *reward,
+               uint8_t *done, float *obs_g, float *reward_g, int32_t *status, void *stream) {
+    if (int rc = check_step_args(e, actions, na, obs, reward, done)) return rc;
+    if (nsteps < 1 || nsteps > 4096) return fail(-1, "rr_rollout: nsteps must be in 1..4096");
+    if (e->custom_prog || e->track_prior)
+        return fail(-1, "rr_rollout: the side kernels of a custom reward program / prior-step tracking bracket single steps; use rr_step");
+    return step_impl<float>(e, actions, nullptr, na, obs, reward, done, obs_g, reward_g, status, stream, (int)nsteps, repeat != 0);
 }
 int rr_step_thrust(rr_env *e, const float *thrust, int32_t nk, float *obs, float *reward, uint8_t *done, float *obs_g,
                    float *reward_g, int32_t *status, void *stream) {

@@ -197,6 +197,34 @@ class BatchedRoboRugbyEnv:
             obs, obs_g = self.get_game_state(1), (self.get_game_state(-1) if self.has_grumpy else None)
         return obs, rew, done.view(torch.bool), DebugInfo(obs_g, rew_g, status)
 
+    def rollout(self, actions, repeat=None, out=None):
+        """Open-loop rollout in ONE launch: `actions` int [S, N] / [S, N, NA] steps the batch S times (or, with
+        `repeat=S`, int [N] / [N, NA] is applied S times: action repeat / frame skip).  Returns (obs [S,N,11],
+        reward [S,N], done [S,N], DebugInfo with [S,...] members): bit-identical to S step() calls, but no arena waits
+        for the slowest arena of the batch between steps.  Build-side extension (rr_rollout); the reference's gym API steps
+        one call at a time."""
+        N = self.num_envs
+        a = torch.as_tensor(actions, device=self.device).to(torch.int32)
+        if repeat is not None:
+            S = int(repeat)
+            a = (a.view(N, 1) if a.dim() == 1 else a).contiguous()
+            na, rep = a.shape[1], 1
+        else:
+            if a.dim() == 2:
+                a = a.unsqueeze(-1)
+            a = a.contiguous()
+            S, na, rep = a.shape[0], a.shape[2], 0
+        if a.shape[-2] != N or self.action_mode != "discrete" or self.obs_kind != 0:
+            raise ValueError("rollout: discrete actions [S,N(,NA)] and the default observer only")
+        if out is None:
+            out = (self._new((S, N, 11), torch.float32), self._new((S, N), torch.float32), self._new((S, N), torch.uint8),
+                   self._new((S, N, 11), torch.float32) if self.has_grumpy else None, self._new((S, N), torch.float32),
+                   self._new((S, N), torch.int32))
+        obs, rew, done, obs_g, rew_g, status = out
+        _lib.check(self._lib.rr_rollout(self._h, _ptr(a), na, S, rep, _ptr(obs), _ptr(rew), _ptr(done), _ptr(obs_g), _ptr(rew_g),
+                                        _ptr(status), self._stream()), "rr_rollout")
+        return obs, rew, done.view(torch.bool), DebugInfo(obs_g, rew_g, status)
+
     def step_thrust(self, thrust):
         """GameEnv.step with continuous (L,R) thrust pairs (RR_EnvBase.py:260-273): float tensor [N, 2*k]."""
         N = self.num_envs

@@ -111,3 +111,35 @@ def test_full_size_rollout_independent_of_shortcuts_and_dispatch_order():
         finals.append((o.cpu().numpy(), rew.cpu().numpy(), st["robots"].cpu().numpy(), st["balls"].cpu().numpy(), st["robots_i"].cpu().numpy()))
     for x, y in zip(*finals):
         assert np.array_equal(x, y, equal_nan=True)
+
+
+@pytest.mark.parametrize("preset", ["T", "G"])
+def test_rollout_in_one_launch_equals_step_by_step(preset):
+    """rr_rollout (S steps per launch, the record stays in LDS) against S rr_step calls: every per-step output and the final
+    state bit-identical, across an episode boundary (auto-reset inside the launch) and with action repeat."""
+    import roborugby_amd as rr
+    n, S = 4096, 9
+    na = rr.PRESETS[preset].nr
+    gen = torch.Generator(device="cuda"); gen.manual_seed(4)
+    acts = torch.randint(0, 8, (S, n, na), generator=gen, device="cuda", dtype=torch.int32)
+    envs = [rr.BatchedRoboRugbyEnv(n, preset=preset, seed=11) for _ in range(3)]
+    for e in envs:
+        e.reset()
+        st = e.get_state()
+        st["step"][: n // 2] = e.preset.game_len_steps - 4  # half of the arenas finish (and are re-placed) inside the rollout
+        e.set_state(st["robots"], st["robots_i"], st["balls"], st["step"])
+    ref = [envs[0].step(acts[s]) for s in range(S)]
+    o, r, d, info = envs[1].rollout(acts)
+    for s in range(S):
+        assert torch.equal(o[s], ref[s][0]) and torch.equal(r[s], ref[s][1]) and torch.equal(d[s], ref[s][2]), (preset, s)
+        assert torch.equal(info.status[s], ref[s][3].status) and torch.equal(info.dblGrumpyScore[s], ref[s][3].dblGrumpyScore)
+        if info.adblGrumpyState is not None:
+            assert torch.equal(info.adblGrumpyState[s], ref[s][3].adblGrumpyState)
+    a, b = envs[0].get_state(), envs[1].get_state()
+    assert all(torch.equal(a[k], b[k]) or (a[k].dtype.is_floating_point and torch.equal(a[k].nan_to_num(7e77), b[k].nan_to_num(7e77))) for k in a)
+    assert int(d.sum()) >= n // 2  # the episode boundary really was inside
+    # action repeat (frame skip): the same action S times
+    rep = [envs[0].step(acts[0]) for _ in range(4)]
+    o2, r2, d2, _ = envs[1].rollout(acts[0], repeat=4)
+    assert all(torch.equal(o2[s], rep[s][0]) and torch.equal(r2[s], rep[s][1]) for s in range(4))
+    del envs
