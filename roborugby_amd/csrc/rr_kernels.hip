@@ -63,7 +63,9 @@ template <class C> constexpr int lds_waves_per_simd() {
 }
 
 
-template <class C, typename O>
+// MULTI = false: rr_step, one step per launch (nsteps, repeat unused); true: rr_rollout's loop over nsteps.  Separate
+// instantiations: the loop around step_arena costs the single-step kernel 12 % (measured) through register allocation alone.
+template <class C, typename O, bool MULTI>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void k_step(SimParams<typename C::Real> sp, typename C::Real *recs,
                                                               int32_t *irecs, int n, const int32_t *actions,
                                                               const float *thrust, int na, O *obs, O *reward,
@@ -86,17 +88,24 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
     load_record(A, rec, irec);
     derive(A, sp);
     RR_STAMP(12);
-    // nsteps consecutive GameEnv.step calls on the record held in LDS (rr_rollout; rr_step is nsteps = 1): step s reads its
-    // actions at [s][arena] (or the same ones again when `repeat`) and writes its outputs at [s][arena]
-#pragma unroll 1
-    for (int s = 0; s < nsteps; s++) {
-        const size_t so = (size_t)s * (size_t)n;
-        StepOut<O> o = { obs + so * 11, obs_g ? obs_g + so * 11 : nullptr, reward + so, reward_g ? reward_g + so : nullptr, done + so,
-                         status ? status + so : nullptr, sp.memo ? reinterpret_cast<uint32_t *>(recs) : nullptr, irecs, arena,
+    if constexpr (!MULTI) {
+        StepOut<O> o = { obs, obs_g, reward, reward_g, done, status, sp.memo ? reinterpret_cast<uint32_t *>(recs) : nullptr, irecs, arena,
                          (int)(Arena<C>::P_STRIDE * sizeof(typename C::Real) / 4), (int)Arena<C>::I_STRIDE };
-        const size_t ao = repeat ? 0 : so;
-        step_arena<C, O>(A, sp, sp.arena_offset + (uint64_t)arena, actions ? actions + (ao + (size_t)arena) * na : nullptr,
-                         thrust ? thrust + (ao + (size_t)arena) * 2 * na : nullptr, na, o);
+        step_arena<C, O>(A, sp, sp.arena_offset + (uint64_t)arena, actions ? actions + (size_t)arena * na : nullptr,
+                         thrust ? thrust + (size_t)arena * 2 * na : nullptr, na, o);
+    } else {
+        // nsteps consecutive GameEnv.step calls on the record held in LDS (rr_rollout): step s reads its actions at
+        // [s][arena] (or the same ones again when `repeat`) and writes its outputs at [s][arena]
+#pragma unroll 1
+        for (int s = 0; s < nsteps; s++) {
+            const size_t so = (size_t)s * (size_t)n;
+            StepOut<O> o = { obs + so * 11, obs_g ? obs_g + so * 11 : nullptr, reward + so, reward_g ? reward_g + so : nullptr, done + so,
+                             status ? status + so : nullptr, sp.memo ? reinterpret_cast<uint32_t *>(recs) : nullptr, irecs, arena,
+                             (int)(Arena<C>::P_STRIDE * sizeof(typename C::Real) / 4), (int)Arena<C>::I_STRIDE };
+            const size_t ao = repeat ? 0 : so;
+            step_arena<C, O>(A, sp, sp.arena_offset + (uint64_t)arena, actions ? actions + (ao + (size_t)arena) * na : nullptr,
+                             thrust ? thrust + (ao + (size_t)arena) * 2 * na : nullptr, na, o);
+        }
     }
     RR_TR();
     {   // the record addresses again, from an arena index the optimiser cannot tie to the first one: otherwise the two
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
     }
     RR_STAMP(13);
     if (cost && threadIdx.x == 0) { // what this group cost, in shader clocks / 256 (saturating): next step's dispatch key
-        const unsigned long long dt = ((__builtin_amdgcn_s_memtime() - t_begin) >> 8) / (unsigned)nsteps; // per step
+        const unsigned long long dt = ((__builtin_amdgcn_s_memtime() - t_begin) >> 8) / (unsigned)(MULTI ? nsteps : 1); // per step
         cost[group] = dt > 0xFFFFull ? 0xFFFFu : (uint32_t)dt;
     }
 #if defined(RR_PROFILE_PHASES)
@@ -540,9 +549,14 @@ static int step_impl(rr_env *e, const int32_t *actions, const float *thrust, int
         } else {
             if (e->custom_prog || e->track_prior)
                 hipLaunchKernelGGL((k_extras_begin<CC>), dim3((n + 127) / 128), dim3(128), 0, s, (const RR *)e->recs, n, (RR *)e->xs, (const uint8_t *)nullptr);
-            hipLaunchKernelGGL((k_step<CC, O>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (RR *)e->recs, e->irecs, n,
-                               actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status, (const uint32_t *)e->order, e->cost,
-                               nsteps, repeat);
+            if (nsteps == 1)
+                hipLaunchKernelGGL((k_step<CC, O, false>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (RR *)e->recs, e->irecs, n,
+                                   actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status, (const uint32_t *)e->order, e->cost,
+                                   1, 0);
+            else if constexpr (std::is_same<O, float>::value)
+                hipLaunchKernelGGL((k_step<CC, O, true>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (RR *)e->recs, e->irecs, n,
+                                   actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status, (const uint32_t *)e->order, e->cost,
+                                   nsteps, repeat);
             if (e->order) hipLaunchKernelGGL(k_order, dim3(1), dim3(ORDER_THREADS), 0, s, (const uint32_t *)e->cost, e->order, e->ngroups);
             if (e->custom_prog)
                 hipLaunchKernelGGL((k_extras_end<CC, O>), dim3((n + 127) / 128), dim3(128), 0, s, params_of<RR>(e),
