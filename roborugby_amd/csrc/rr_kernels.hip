@@ -553,10 +553,12 @@ static int step_impl(rr_env *e, const int32_t *actions, const float *thrust, int
                 hipLaunchKernelGGL((k_step<CC, O, false>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (RR *)e->recs, e->irecs, n,
                                    actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status, (const uint32_t *)e->order, e->cost,
                                    1, 0);
-            else if constexpr (std::is_same<O, float>::value)
+            else if constexpr (std::is_same<O, float>::value && (CC::NR == 1 ? CC::VW == 2 : CC::VW == 8)) // default lane widths only (build time)
                 hipLaunchKernelGGL((k_step<CC, O, true>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (RR *)e->recs, e->irecs, n,
                                    actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status, (const uint32_t *)e->order, e->cost,
                                    nsteps, repeat);
+            else
+                return fail(-1, "rr_rollout: built for float outputs and the default lane widths (RR_VW unset) only");
             if (e->order) hipLaunchKernelGGL(k_order, dim3(1), dim3(ORDER_THREADS), 0, s, (const uint32_t *)e->cost, e->order, e->ngroups);
             if (e->custom_prog)
                 hipLaunchKernelGGL((k_extras_end<CC, O>), dim3((n + 127) / 128), dim3(128), 0, s, params_of<RR>(e),
