@@ -143,3 +143,32 @@ def test_rollout_in_one_launch_equals_step_by_step(preset):
     o2, r2, d2, _ = envs[1].rollout(acts[0], repeat=4)
     assert all(torch.equal(o2[s], rep[s][0]) and torch.equal(r2[s], rep[s][1]) for s in range(4))
     del envs
+
+
+def test_step_can_be_captured_into_a_hip_graph():
+    """rr_step only enqueues kernels on the caller's stream (no synchronisation, allocation or copy), so a step with
+    preallocated outputs can be captured once and replayed: same results as eager calls."""
+    import roborugby_amd as rr
+    n = 8192
+    gen = torch.Generator(device="cuda"); gen.manual_seed(2)
+    acts = torch.randint(0, 8, (12, n, 4), generator=gen, device="cuda", dtype=torch.int32)
+    eager, graphed = rr.BatchedRoboRugbyEnv(n, preset="G", seed=5), rr.BatchedRoboRugbyEnv(n, preset="G", seed=5)
+    eager.reset(); graphed.reset()
+    a_buf = acts[0].clone()
+    out = (torch.empty(n, 11, device="cuda"), torch.empty(n, device="cuda"), torch.empty(n, dtype=torch.uint8, device="cuda"),
+           torch.empty(n, 11, device="cuda"), torch.empty(n, device="cuda"), torch.empty(n, dtype=torch.int32, device="cuda"))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graphed.step(a_buf, out=out)  # warm-up on the side stream, as torch's capture protocol asks
+    torch.cuda.current_stream().wait_stream(side)
+    ref0 = eager.step(acts[0])
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        graphed.step(a_buf, out=out)
+    for s in range(1, 12):  # (the capture itself executed nothing: the warm-up was step 0)
+        a_buf.copy_(acts[s])
+        g.replay()
+        o, r, d, info = eager.step(acts[s])
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], o) and torch.equal(out[1], r) and torch.equal(out[2].bool(), d) and torch.equal(out[5], info.status), s
