@@ -338,6 +338,8 @@ template <class C> struct ArenaBody {
     R exc[NB];                // how far (L1) the contact responses of this sub-step have carried the ball from its frame-begin centre
     R reach[NB];              // 14.04 + the most the ball can travel in this sub-step's roll: the ball-ball bound of the fused roll phase
     int32_t sides_ok; // sm/sc match the current robot poses (rebuilt lazily by the first phase that needs them)
+    uint8_t wm[NR];   // how the robot's last move met the walls: bit 0 = blocked (reverted), bit 1 = clamped (the island freeze
+                      // compares it); bytes, so that it fits the alignment hole behind sides_ok (the slice is at its 8-waves-per-CU limit)
     union { // the lidar candidates are only alive inside observe(), the inner-square offsets only inside a sub-step
         R irel[NR][9];                    // corner offsets of the ball's inner square at rot+45 (diameter end points)
         R lidar[2][3 * NR];               // [front|back][ray, rect] minima over the rect's four sides
@@ -465,12 +467,14 @@ template <class C> RR_HD void ball_shift(Arena<C> &A, int b, typename C::Real dx
 template <typename R> RR_HD bool rob_hit_wall(const FR<R> &f, const SimParams<R> &sp) {
     return f.l < (R)0 || f.r > sp.W || f.t <= (R)0 || f.b >= sp.H;
 }
-template <typename R> RR_HD void rob_clamp(FR<R> &f, const SimParams<R> &sp) {
+template <typename R> RR_HD bool rob_clamp(FR<R> &f, const SimParams<R> &sp) {
     const R buffer = (R).5;
-    if (f.l < (R)0) fr_set_left<R>(f, buffer);
-    if (f.r > sp.W) fr_set_right<R>(f, sp.W - buffer);
-    if (f.t <= (R)0) fr_set_top<R>(f, buffer);
-    if (f.b >= sp.H) fr_set_bottom<R>(f, sp.H - buffer);
+    bool any = false;
+    if (f.l < (R)0) { fr_set_left<R>(f, buffer); any = true; }
+    if (f.r > sp.W) { fr_set_right<R>(f, sp.W - buffer); any = true; }
+    if (f.t <= (R)0) { fr_set_top<R>(f, buffer); any = true; }
+    if (f.b >= sp.H) { fr_set_bottom<R>(f, sp.H - buffer); any = true; }
+    return any;
 }
 // Robot.move (RR_Robot.py:106-108,139-234).  Lanes of one wavefront drive robots with different thrust patterns; the
 // three trig evaluations a move can need (heading or pivot direction, the rotation setter's 360-rot, the re-centring
@@ -505,11 +509,13 @@ RR_HD void robot_move_finish(Arena<C> &A, const SimParams<typename C::Real> &sp,
     using R = typename C::Real;
     FR<R> f = load_robot(A, r);
     const R rot_prior = f.rot, px = f.cx, py = f.cy;
+    bool blocked;
     if (m.lin) {
         const R vel = m.L < 0 ? (R)-1 : (R)1;
         fr_set_left<R>(f, f.l + c1 * vel);
         fr_set_top<R>(f, f.t + s1 * vel * (R)-1);
-        if (rob_hit_wall<R>(f, sp)) { fr_set_cx<R>(f, px); fr_set_cy<R>(f, py); }
+        blocked = rob_hit_wall<R>(f, sp);
+        if (blocked) { fr_set_cx<R>(f, px); fr_set_cy<R>(f, py); }
     } else {
         if (m.nrot != f.rot) {
             f.rot = m.nrot;
@@ -522,7 +528,8 @@ RR_HD void robot_move_finish(Arena<C> &A, const SimParams<typename C::Real> &sp,
             fr_set_cx<R>(f, cpx + (R)16 * c3);
             fr_set_cy<R>(f, cpy - (R)16 * s3);
         }
-        if (rob_hit_wall<R>(f, sp)) {
+        blocked = rob_hit_wall<R>(f, sp);
+        if (blocked) {
             fr_set_cx<R>(f, px); fr_set_cy<R>(f, py);
             // `self.rectDbl.rotation = dblPriorRot` (RR_Robot.py:226): the setter on (rot_prior + 720) % 360.  The
             // normalised value is almost always rot_prior itself (it came out of this very normalisation one move ago),
@@ -540,8 +547,9 @@ RR_HD void robot_move_finish(Arena<C> &A, const SimParams<typename C::Real> &sp,
             }
         }
     }
-    rob_clamp<R>(f, sp);
+    const bool clamped = rob_clamp<R>(f, sp);
     store_robot(A, r, f);
+    A.wm[r] = (uint8_t)((blocked ? 1 : 0) | (clamped ? 2 : 0));
 }
 // one robot's whole move on one lane (thaw / edge replay of the island freeze, and configurations without a lane pair
 // per robot); substep_phase1 spreads the same arithmetic over a pair of lanes
@@ -549,7 +557,7 @@ template <class C> RR_HD void robot_move_lane(Arena<C> &A, const SimParams<typen
     using R = typename C::Real;
     const MovePlan<R> m = robot_move_plan(A, r);
     A.i.mc[r] += 1;
-    if (m.idle) return;
+    if (m.idle) { A.wm[r] = 0; return; }
     R s1, c1, s2, c2, s3, c3;
     m_sincos(radians<R>(m.a1), s1, c1);
     m_sincos(radians<R>(m.a2), s2, c2);
@@ -1257,7 +1265,7 @@ RR_HDN void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real>
 // the two fast phases of a sub-step (see substep); FZ: an island is frozen
 template <class C, bool FZ>
 RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, const Hit &fz, uint32_t prev_moved, uint64_t &m_rr,
-                          uint64_t &m_br) {
+                          uint64_t &m_br, uint64_t &m_wm) {
     using R = typename C::Real;
     // A robot's move is spread over a PAIR of lanes (2r, 2r+1) when the virtual wave has them: both lanes run the same
     // instructions on different data -- two of the three sin/cos evaluations at once, then one renormalised corner each --
@@ -1269,7 +1277,10 @@ RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, co
     RR_FOR_LANES(l) {
         bool c_rr = false, c_br = false;
         const int r = PAIRED ? (l >> 1) : l, part = PAIRED ? (l & 1) : 0;
-        const bool robot_lane = r < C::NR && !(FZ && ((fz.r >> (r < C::NR ? r : 0)) & 1u));
+        // a frozen robot still makes its move here (and is put back at the end of the sub-step): how the move meets the walls
+        // depends on the robot's incrementally kept edges, so it is re-evaluated, not assumed; only its pair tests are skipped
+        const bool robot_lane = r < C::NR;
+        const bool own = robot_lane && !(FZ && ((fz.r >> (r < C::NR ? r : 0)) & 1u));
         if (robot_lane && part == 0) {
             if (prev_moved & (1u << r)) { A.p.px[r] = A.ax[r]; A.p.py[r] = A.ay[r]; A.p.prot[r] = A.arot[r]; }
             // on_frame_begin (RR_Robot.py:119-120): the ring entry written this frame
@@ -1277,10 +1288,14 @@ RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, co
             A.ax[r] = ox; A.ay[r] = oy; A.arot[r] = A.p.rrot[r];
             for (int j = 0; j < C::NR; j++) { // robot-robot: needs centres within 2 x 22.36 (+ 2 x 3 px of motion)
                 R dx = A.p.rcx[j] - ox, dy = A.p.rcy[j] - oy;
-                // each pair once (j > r); a frozen j has no lane of its own in this phase, so its partner tests the pair
-                c_rr = c_rr | (((j > r) | (FZ && ((fz.r >> j) & 1u) != 0)) & (j != r) & (dx * dx + dy * dy <= (R)(51.5 * 51.5)));
+                // each pair once (j > r); a frozen robot tests nothing itself, so its partner outside the island tests the pair
+                c_rr = c_rr | (own & ((j > r) | (FZ && ((fz.r >> j) & 1u) != 0)) & (j != r) & (dx * dx + dy * dy <= (R)(51.5 * 51.5)));
             }
-            if (!PAIRED) robot_move_lane(A, sp, r); // _move_bots
+            if (!PAIRED) { // _move_bots
+                const int wm_before = FZ ? A.wm[r] : 0;
+                robot_move_lane(A, sp, r);
+                if (FZ && !own && A.wm[r] != wm_before) c_rr = true; // a frozen robot met the walls differently: thaw
+            }
         }
         if (PAIRED) {
             R s_ = (R)0, c_ = (R)1;
@@ -1318,7 +1333,7 @@ RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, co
             const R ps = RR_XOR1(sv, l), pc = RR_XOR1(cv, l);
             const R s2 = part ? RR_LV(sv, l) : ps, c2 = part ? RR_LV(cv, l) : pc;
             R ax = (R)0, ay = (R)0;
-            if (r < C::NR && !(FZ && ((fz.r >> (r < C::NR ? r : 0)) & 1u))) {
+            if (r < C::NR) {
                 corner_from_sc<R>(RR_LV(mp, l).nrot, s2, c2, part ? (R)10 : (R)-10, (R)-20, sp.rob_cdist, ax, ay);
             }
             RR_LV(qx, l) = ax; RR_LV(qy, l) = ay;
@@ -1326,15 +1341,21 @@ RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, co
         RR_FOR_LANES(l) {
             const int r = l >> 1, part = l & 1;
             const R trx = RR_XOR1(qx, l), try_ = RR_XOR1(qy, l); // the odd lane's corner (TR), seen from the even lane
-            if (part == 0 && r < C::NR && !(FZ && ((fz.r >> (r < C::NR ? r : 0)) & 1u))) {
+            bool wm_changed = false;
+            if (part == 0 && r < C::NR) {
                 const MovePlan<R> m = RR_LV(mp, l);
+                const int wm_before = FZ ? A.wm[r] : 0;
                 A.i.mc[r] += 1;
                 if (!m.idle) {
                     R s3, c3;
                     m_sincos(radians<R>(m.a3), s3, c3);
                     robot_move_finish(A, sp, r, m, RR_LV(sv, l), RR_LV(cv, l), s3, c3, RR_LV(qx, l), RR_LV(qy, l), trx, try_);
+                } else {
+                    A.wm[r] = 0;
                 }
+                if (FZ) wm_changed = ((fz.r >> r) & 1u) && A.wm[r] != wm_before; // the frozen robot met the walls differently
             }
+            if (FZ) RR_VOTE(m_wm, l, wm_changed);
         }
     }
 }
@@ -1380,14 +1401,11 @@ RR_HD void push_balls(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32
         RR_SYNC();
     }
 }
-// the frozen island catches up with phase 1: frame hooks of its robots and balls, and the robots' moves
+// the frozen island rejoins the sub-step: its robots have already made their move in phase 1, its balls run the frame
+// hooks they skipped
 template <class C> RR_HD void thaw_island(Arena<C> &A, const SimParams<typename C::Real> &sp, Hit &fz, uint32_t &bots_moved) {
     using R = typename C::Real;
     RR_FOR_LANES(l) {
-        if (l < C::NR && ((fz.r >> l) & 1u)) { // (no ring update: a frozen robot's previous move was undone)
-            A.ax[l] = A.p.rcx[l]; A.ay[l] = A.p.rcy[l]; A.arot[l] = A.p.rrot[l];
-            robot_move_lane(A, sp, l);
-        }
         if (l < C::NB && ((fz.b >> l) & 1u)) {
             A.bmass[l] = 1; A.bfx[l] = (R)0; A.bfy[l] = (R)0; A.exc[l] = (R)0;
             A.pfx[l] = ball_copy_c<R>(A.p.bcx[l]); A.pfy[l] = ball_copy_c<R>(A.p.bcy[l]);
@@ -1430,13 +1448,13 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     // phase 1: frame hooks, robot moves AND the exact broad phase.  The broad phase runs in the same phase as the moves:
     // it may see a robot centre from before or after this sub-step's move, so its bounds carry the largest centre
     // displacement a move can cause (1 px drive / 0.17 px pivot / <= 1.5 px wall clamp: 3 px per robot is generous).
-    uint64_t m_rr = 0, m_br = 0;
+    uint64_t m_rr = 0, m_br = 0, m_wm = 0;
     const bool frozen = (fz.r | fz.b) != 0; // the frozen variants are separate instantiations: the common path pays nothing
-    if (frozen) substep_phase1<C, true>(A, sp, fz, prev_moved, m_rr, m_br);
-    else substep_phase1<C, false>(A, sp, fz, prev_moved, m_rr, m_br);
+    if (frozen) substep_phase1<C, true>(A, sp, fz, prev_moved, m_rr, m_br, m_wm);
+    else substep_phase1<C, false>(A, sp, fz, prev_moved, m_rr, m_br, m_wm);
     RR_SYNC();
     RR_STAMP(1);
-    if ((fz.r | fz.b) && (m_rr | m_br)) { // thaw before anything depended on the island
+    if ((fz.r | fz.b) && (m_rr | m_br | m_wm)) { // thaw before anything depended on the island
         RR_TRACE("E thaw in phase 1\n");
         thaw_island(A, sp, fz, bots_moved);
         m_rr = 1; m_br = 1;
@@ -1479,13 +1497,9 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
         if (!rr_ok_) { work += 8; undo_naughty_movement(A, sp, balls_moved, bots_moved, st, hit); }
     }
     RR_STAMP(6);
-    if (fz.r) { // still frozen: the island's robots would have moved and been undone -- replay that arithmetic on their records
+    if (fz.r) { // still frozen: the island's robots made their move in phase 1; the undo they would have met puts them back
         RR_FOR_LANES(l) {
-            if (l < C::NR && ((fz.r >> l) & 1u)) {
-                A.ax[l] = A.p.rcx[l]; A.ay[l] = A.p.rcy[l]; A.arot[l] = A.p.rrot[l];
-                robot_move_lane(A, sp, l);
-                robot_undo_lane(A, sp, l);
-            }
+            if (l < C::NR && ((fz.r >> l) & 1u)) robot_undo_lane(A, sp, l);
         }
         RR_SYNC();
     }
@@ -1862,17 +1876,14 @@ template <typename O> struct StepOut {
 // same bits into `naughty` / `st`): the loop can stop.  Exact, not approximate.
 // The comparison is bitwise (NaN-safe), lane-strided, against a snapshot kept in the arena's own HBM record (dead
 // between load_record and store_record); it is only made after sub-steps that ran the expensive contact paths.
-// the robots in `mask` keep their AABB at least 6 px inside the arena: a move shifts an edge by < 2 px, so the wall test /
-// clamp of their move (RR_Robot.py:188-203) cannot fire and cannot depend on the last bits of the edges
-template <class C> RR_HD bool robots_clear_of_walls(const Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t mask) {
-    using R = typename C::Real;
-    uint64_t near = 0;
+// did the last move of any robot in `mask` end in the 0.5-px wall clamp (RR_Robot.py:195-203)?
+template <class C> RR_HD bool robots_clamped(const Arena<C> &A, uint32_t mask) {
+    uint64_t any = 0;
     RR_FOR_LANES(l) {
-        const bool nw = (l < C::NR) && ((mask >> l) & 1u) &&
-                        !(A.p.rl[l] > (R)6 && A.p.rrt[l] < sp.W - (R)6 && A.p.rt[l] > (R)6 && A.p.rb[l] < sp.H - (R)6);
-        RR_VOTE(near, l, nw);
+        const bool c = (l < C::NR) && ((mask >> l) & 1u) && (A.wm[l] & 2);
+        RR_VOTE(any, l, c);
     }
-    return !near;
+    return any != 0;
 }
 // cheap necessary condition, from LDS only: every robot ends the sub-step on its frame-begin pose (undone, blocked or idle)
 template <class C> RR_HD bool robots_unmoved(const Arena<C> &A) {
@@ -1921,9 +1932,9 @@ RR_HD void snapshot_compare_update(const Arena<C> &A, uint32_t *snap, int32_t *i
                 axd = axd | d;
             }
         }
-        for (int k = l; k < C::NR; k += C::VW) {
-            const int32_t v = A.i.mc[k];
-            mine |= (!have || isnap[k] != v) ? (1u << k) : 0u;
+        for (int k = l; k < 2 * C::NR; k += C::VW) { // move counters, then how each robot's last move met the walls
+            const int32_t v = k < C::NR ? A.i.mc[k] : A.wm[k - C::NR];
+            mine |= (!have || isnap[k] != v) ? (1u << (k % C::NR)) : 0u;
             isnap[k] = v;
         }
         RR_VOTE(any_ax, l, axd);
@@ -2035,11 +2046,13 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
                 }
                 // the island: everything that took part in a hit.  Unchanged since the previous sub-step, its robots'
                 // moves undone in both (so neither the ring update nor ax/ay/arot matter to it) -> freeze it.  A robot's
-                // AABB edges may keep drifting in the last bits (move + undo, incremental); nothing but the wall test of
-                // its own move reads them, so a robot clear of the walls may be frozen and its edge arithmetic replayed.
+                // AABB edges may keep drifting in the last bits (move + undo, incremental); nothing but the wall test / clamp of
+                // its own move reads them.  So a frozen robot keeps making its move and being put back -- on its real edges --
+                // and the island is thawed the moment that move meets the walls differently (wm); a move that was clamped
+                // (its centre then depends on an edge value) is never frozen.
                 // (a one-robot arena is its own island: the whole-arena test above already covers it)
                 if (C::NR > 1 && (hit.r | hit.b) && !(chg_r & hit.r) && !(chg_b & hit.b) && !((prev_moved | snap_moved) & hit.r) &&
-                    robots_clear_of_walls(A, sp, hit.r)) {
+                    !robots_clamped(A, hit.r)) {
                     RR_TRACE("E freeze robots %x balls %x after sub-step %d\n", hit.r, hit.b, f);
                     fz = hit;
                 }

@@ -22,7 +22,7 @@ template <class C> struct Emu {
     bool custom_prog;
     uint32_t snap[Arena<C>::P_STRIDE * sizeof(typename C::Real) / 4];
     typename C::Real xs[3 * C::NR + 1 + 2 * C::NB]; // on_step_begin snapshot (always taken here: AllCoords_WithPrior reads it)
-    int32_t isnap[C::NR];
+    int32_t isnap[2 * C::NR];
 };
 
 template <typename R> static void fill_params(SimParams<R> &sp, double W, double H, int game_len, int game_mode,

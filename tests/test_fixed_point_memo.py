@@ -94,10 +94,12 @@ def test_shortcut_exact_on_the_squeezed_fixture_G():
     assert on == off
 
 
-def test_island_freeze_exact_on_stuck_islands_from_a_rollout_G():
-    """40 arenas taken from the slowest wavefronts of a 65,536-arena random rollout on the MI355X (a ball squeezed between
-    robots, robots pushing a ball into each other): the freeze fires on them and changes nothing."""
-    d = np.load(os.path.join(HERE, "data", "stuck_islands_G.npz"))
+@pytest.mark.parametrize("fixture", ["stuck_islands_G.npz", "stuck_islands_wall_G.npz"])
+def test_island_freeze_exact_on_stuck_islands_from_a_rollout_G(fixture):
+    """Arenas taken from the slowest wavefronts of a 65,536-arena random rollout on the MI355X -- a ball squeezed between
+    robots, robots pushing a ball into each other (step ~30-140), and, late in the episode (step ~2,800), robots within a
+    few pixels of a wall pushing a ball into it: the freeze fires on them and changes nothing."""
+    d = np.load(os.path.join(HERE, "data", fixture))
     fired = {"freeze": 0, "thaw in phase 1": 0}
     for a in range(len(d["step"])):
         state = (d["robots"][a], d["robots_i"][a], d["balls"][a], int(d["step"][a]))

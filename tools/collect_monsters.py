@@ -7,6 +7,7 @@ import roborugby_amd as rr
 from roborugby_amd import _lib
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 thr_us = float(sys.argv[2]) if len(sys.argv) > 2 else 450.0
+skip = int(sys.argv[3]) if len(sys.argv) > 3 else 20  # steps to run before collecting
 n = 65536
 env = rr.BatchedRoboRugbyEnv(n, preset="G", seed=0)
 env.reset()
@@ -16,9 +17,9 @@ waves = n // 8
 buf = (C.c_ulonglong * (2 * waves))()
 order_cap = None
 found = []
-for s in range(steps):
+for s in range(skip + steps):
     a = torch.randint(0, 8, (n, 4), generator=g, device='cuda', dtype=torch.int32)
-    before = env.get_state() if s >= 20 else None
+    before = env.get_state() if s >= skip else None
     env.step(a); torch.cuda.synchronize()
     if before is None: continue
     assert lib.rr_debug_wave_times(buf, waves) == 0
