@@ -132,13 +132,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
 // slow one may start in the last round and the chip idles behind it -- measured: 345 us of work per launch stretched
 // to ~500 us.  Contact situations persist over steps, so last step's duration is a good key.  One workgroup, counting
 // sort of the per-group costs into descending order (ties in arbitrary order: results never depend on the order).
+#ifndef RR_ORDER_SHIFT
+#define RR_ORDER_SHIFT 2 // cost unit is 256 clocks: 1,024 clocks per bin
+#endif
 constexpr int ORDER_BINS = 1024, ORDER_THREADS = 1024;
 __global__ __launch_bounds__(ORDER_THREADS) void k_order(const uint32_t *cost, uint32_t *order, int ngroups) {
     __shared__ uint32_t hist[ORDER_BINS];
     for (int i = threadIdx.x; i < ORDER_BINS; i += ORDER_THREADS) hist[i] = 0;
     __syncthreads();
     for (int g = threadIdx.x; g < ngroups; g += ORDER_THREADS) {
-        uint32_t c = cost[g] >> 2; // 1,024 clocks per bin: 0 .. ~1M clocks (0.4 ms) resolved, slower groups share the first bin
+        uint32_t c = cost[g] >> RR_ORDER_SHIFT; // 1,024 clocks per bin: 0 .. ~1M clocks (0.4 ms) resolved, slower groups share the first bin
         c = c > ORDER_BINS - 1 ? ORDER_BINS - 1 : c;
         atomicAdd(&hist[ORDER_BINS - 1 - c], 1u);
     }
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order(const uint32_t *cost, u
     hist[threadIdx.x] = scan[threadIdx.x] - v; // start offset of the bin
     __syncthreads();
     for (int g = threadIdx.x; g < ngroups; g += ORDER_THREADS) {
-        uint32_t c = cost[g] >> 2;
+        uint32_t c = cost[g] >> RR_ORDER_SHIFT;
         c = c > ORDER_BINS - 1 ? ORDER_BINS - 1 : c;
         order[atomicAdd(&hist[ORDER_BINS - 1 - c], 1u)] = (uint32_t)g;
     }
