@@ -5,7 +5,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "rr_kernels.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "rr_sim.hpp"), os.path.join(os.path.dirname(HERE), "include", "roborugby_amd.h")]
+DEPS = [SRC, os.path.join(HERE, "csrc", "rr_sim.hpp"), os.path.join(HERE, "csrc", "rr_extras.hpp"),
+        os.path.join(os.path.dirname(HERE), "include", "roborugby_amd.h")]
 LIB = os.path.join(HERE, "libroborugby_amd.so")
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
