@@ -42,7 +42,7 @@ class BatchedDQNAgent:
 
     def __init__(self, gamma=.99, epsilon=1.0, lr=.0005, input_dims=11, batch_size=2500, n_actions=8,
                  max_mem_size=500000, eps_end=0.2, eps_dec=.999997, fc1_dims=256, fc2_dims=256,
-                 target_update_freq=100000, device="cpu", seed=0):
+                 target_update_freq=100000, device="cpu", seed=0, use_graph=True):
         self.gamma, self.epsilon, self.eps_end, self.eps_dec = gamma, epsilon, eps_end, eps_dec
         self.n_actions, self.mem_size, self.batch_size = n_actions, int(max_mem_size), int(batch_size)
         self.target_update_freq = int(target_update_freq)
@@ -54,7 +54,7 @@ class BatchedDQNAgent:
         torch.manual_seed(seed)
         self.Q_eval = DeepQNetwork(lr, input_dims, fc1_dims, fc2_dims, n_actions).to(self.device)
         if self.device.type == "cuda":
-            self.Q_eval.optimizer = torch.optim.Adam(self.Q_eval.parameters(), lr=lr, fused=True)
+            self.Q_eval.optimizer = torch.optim.Adam(self.Q_eval.parameters(), lr=lr, fused=True, capturable=True)
         self.Q_target = copy.deepcopy(self.Q_eval)
         m, d = self.mem_size, self.device
         self.state_memory = torch.zeros(m, input_dims, dtype=torch.float32, device=d)
@@ -63,6 +63,7 @@ class BatchedDQNAgent:
         self.reward_memory = torch.zeros(m, dtype=torch.float32, device=d)
         self.terminal_memory = torch.zeros(m, dtype=torch.bool, device=d)
         self.last_loss = None
+        self.use_graph = bool(use_graph)
 
     @torch.no_grad()
     def choose_action(self, observation, epsilon_override=None):
@@ -92,12 +93,9 @@ class BatchedDQNAgent:
         self.terminal_memory[pos] = done.bool()
         self.mem_cntr += n
 
-    def learn(self):
-        """One gradient step (Training_DQN_pytorch.py:151-191)."""
-        if self.mem_cntr < self.batch_size:
-            return None
-        self.Q_eval.optimizer.zero_grad()
-        max_mem = min(self.mem_size, self.mem_cntr)
+    def _learn_core(self, max_mem):
+        """sampling + TD target + one Adam step (Training_DQN_pytorch.py:156-186); everything on the device, no host sync"""
+        self.Q_eval.optimizer.zero_grad(set_to_none=False)
         batch = torch.randperm(max_mem, generator=self.gen, device=self.device)[:self.batch_size]  # replace=False
         state_batch = self.state_memory[batch]
         new_state_batch = self.new_state_memory[batch]
@@ -107,18 +105,55 @@ class BatchedDQNAgent:
         q_eval = self.Q_eval(state_batch).gather(1, action_batch.view(-1, 1)).squeeze(1)
         with torch.no_grad():
             q_next = self.Q_target(new_state_batch)
-            q_next[terminal_batch] = 0.0
+            q_next = q_next.masked_fill(terminal_batch.view(-1, 1), 0.0)
             q_target = reward_batch + self.gamma * q_next.max(dim=1)[0]
         loss = self.Q_eval.loss(q_target, q_eval)
         loss.backward()
         self.Q_eval.optimizer.step()
+        return loss.detach()
+
+    def _try_capture(self, max_mem):
+        """Once the replay memory is full the learn step has a fixed shape: capture it into a HIP graph (the step is ~25
+        small kernels and launch-bound).  Any failure leaves the eager path in place."""
+        self._graph_tried = True
+        try:
+            g = torch.cuda.CUDAGraph()
+            if hasattr(g, "register_generator_state"):
+                g.register_generator_state(self.gen)
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._learn_core(max_mem)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            with torch.cuda.graph(g):
+                self._graph_loss = self._learn_core(max_mem)
+            self._graph, self._graph_mem = g, max_mem
+        except Exception as ex:  # noqa: BLE001 -- eager is always available
+            self._graph = None
+            print(f"[dqn] learn() stays eager (graph capture failed: {type(ex).__name__}: {ex})", flush=True)
+
+    def learn(self):
+        """One gradient step (Training_DQN_pytorch.py:151-191)."""
+        if self.mem_cntr < self.batch_size:
+            return None
+        max_mem = min(self.mem_size, self.mem_cntr)
+        if self.use_graph and self.device.type == "cuda" and max_mem == self.mem_size and not getattr(self, "_graph_tried", False):
+            self._try_capture(max_mem)
+        if getattr(self, "_graph", None) is not None and self._graph_mem == max_mem:
+            self._graph.replay()
+            loss = self._graph_loss
+        else:
+            loss = self._learn_core(max_mem)
         # the reference syncs when mem_cntr hits a multiple of target_update_freq; with N transitions per call the
         # counter jumps, so sync whenever a multiple has been crossed
         if self.mem_cntr >= self._next_target_sync:
-            self.Q_target.load_state_dict(self.Q_eval.state_dict())
+            with torch.no_grad():  # in place: a captured graph keeps reading these very tensors
+                for pt, pe in zip(self.Q_target.parameters(), self.Q_eval.parameters()):
+                    pt.copy_(pe)
             self._next_target_sync = (self.mem_cntr // self.target_update_freq + 1) * self.target_update_freq
         self.epsilon = max(self.epsilon * self.eps_dec, self.eps_end)
-        self.last_loss = loss.detach()
+        self.last_loss = loss
         return self.last_loss
 
     # whole-agent checkpoint like the reference's pickle (Training_DQN_pytorch.py:373-376), without the replay
