@@ -1435,9 +1435,10 @@ template <class C> RR_HD void thaw_island(Arena<C> &A, const SimParams<typename 
 // for everything outside K and keeps K as an obstacle: its robots with the usual motion slack, its balls with the
 // excursion `exc` their responses reached while the island was last computed.  If every broad test involving an
 // entity outside K stays negative, nothing outside K touched anything (K included) and the sub-step is complete: exact.
-// If any fires, the island is thawed on the spot: its robots make the move they skipped (moves are independent per
-// robot), its balls run their frame hooks (and, if the thaw comes after the roll phase, the push restricted to K and
-// their roll), and the reference-shaped path runs for the whole arena as if it had never been frozen.
+// If any fires, the island is thawed on the spot: its balls run the frame hooks they skipped (and, if the thaw comes
+// after the roll phase, the push restricted to K and their roll), and the reference-shaped path runs for the whole
+// arena as if it had never been frozen.  The island's robots are never held back: they make their real move in phase 1
+// like every robot (how it meets the walls depends on their drifting edges) and are put back at the end of the sub-step.
 template <class C>
 RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &naughty, int &st, uint32_t &prev_moved,
                    int &work, Hit &fz, Hit &hit) {
