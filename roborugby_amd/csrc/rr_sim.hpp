@@ -637,14 +637,14 @@ template <class C> RR_HD bool ball_near_robot(const Arena<C> &A, int b, int r) {
 // bounding box is wide unless the lines coincide to that precision -- in which case no axis separates them.)  Most
 // robot pairs that come within 45.5 px never overlap -- a colliding move is undone -- so this keeps the side-slope
 // cache and the 16-test narrow phase for the real collisions.
-template <class C> RR_HD bool robots_separated(const Arena<C> &A, int i, int j, typename C::Real dx, typename C::Real dy) {
+template <class C>
+RR_HD bool robots_separated(const Arena<C> &A, int i, int j, typename C::Real dx, typename C::Real dy, typename C::Real m = (typename C::Real)0.05) {
     using R = typename C::Real;
     const R *p = A.rel[i], *q = A.rel[j];
     // unit axes (to ~1e-15) from the corner offsets: TL -> TR is 20 long, TL -> BL 40
     const R uix = (p[2] - p[0]) * (R)0.05, uiy = (p[3] - p[1]) * (R)0.05, vix = (p[4] - p[0]) * (R)0.025, viy = (p[5] - p[1]) * (R)0.025;
     const R ujx = (q[2] - q[0]) * (R)0.05, ujy = (q[3] - q[1]) * (R)0.05, vjx = (q[4] - q[0]) * (R)0.025, vjy = (q[5] - q[1]) * (R)0.025;
     const R uu = m_abs(uix * ujx + uiy * ujy), uv = m_abs(uix * vjx + uiy * vjy), vu = m_abs(vix * ujx + viy * ujy), vv = m_abs(vix * vjx + viy * vjy);
-    const R m = (R)0.05;
     const bool s0 = m_abs(dx * uix + dy * uiy) > (R)10 + ((R)10 * uu + (R)20 * uv) + m; // axis u_i
     const bool s1 = m_abs(dx * vix + dy * viy) > (R)20 + ((R)10 * vu + (R)20 * vv) + m; // axis v_i
     const bool s2 = m_abs(dx * ujx + dy * ujy) > (R)10 + ((R)10 * uu + (R)20 * vu) + m; // axis u_j
@@ -1289,7 +1289,12 @@ RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, co
             for (int j = 0; j < C::NR; j++) { // robot-robot: needs centres within 2 x 22.36 (+ 2 x 3 px of motion)
                 R dx = A.p.rcx[j] - ox, dy = A.p.rcy[j] - oy;
                 // each pair once (j > r); a frozen robot tests nothing itself, so its partner outside the island tests the pair
-                c_rr = c_rr | (own & ((j > r) | (FZ && ((fz.r >> j) & 1u) != 0)) & (j != r) & (dx * dx + dy * dy <= (R)(51.5 * 51.5)));
+                bool cl = own & ((j > r) | (FZ && ((fz.r >> j) & 1u) != 0)) & (j != r) & (dx * dx + dy * dy <= (R)(51.5 * 51.5));
+                // (frozen variant only -- it costs the common path nothing: a spurious "close" thaws the island, so the pair also
+                // has to pass the separating-axis test, grown by the 2 x 3 px the two robots can still move; every robot is
+                // still on its frame-begin pose here)
+                if (FZ && PAIRED && cl) cl = !robots_separated(A, r, j, dx, dy, (R)6.05);
+                c_rr = c_rr | cl;
             }
             if (!PAIRED) { // _move_bots
                 const int wm_before = FZ ? A.wm[r] : 0;
@@ -1313,7 +1318,13 @@ RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, co
                 A.reach[l] = (R)14.04 + ((m_abs(A.p.bvx[l]) + m_abs(A.p.bvy[l])) * (R)1.01 + (R)0.02);
                 for (int r2 = 0; r2 < C::NR; r2++) { // ball-robot: 22.36 + 9.9 (+ 3 px of robot motion)
                     R dx = A.p.bcx[l] - A.p.rcx[r2], dy = A.p.bcy[l] - A.p.rcy[r2];
-                    c_br = c_br | (dx * dx + dy * dy <= (R)(36.0 * 36.0));
+                    bool cl = dx * dx + dy * dy <= (R)(36.0 * 36.0);
+                    if (FZ && PAIRED && cl) { // frozen variant only: the robot-frame bound of ball_near_robot, grown by the same 3 px
+                        const R *q = A.rel[r2];
+                        const R ux = (q[2] - q[0]) * (R)0.05, uy = (q[3] - q[1]) * (R)0.05, vx = (q[4] - q[0]) * (R)0.025, vy = (q[5] - q[1]) * (R)0.025;
+                        cl = (m_abs(dx * ux + dy * uy) <= (R)20.05) & (m_abs(dx * vx + dy * vy) <= (R)30.05);
+                    }
+                    c_br = c_br | cl;
                 }
             } else { // frozen ball: anywhere within its recorded excursion, against the robots outside the island
                 const R reach = (R)36.05 + A.exc[l];
