@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RR_ABI_VERSION 1
+#define RR_ABI_VERSION 2
 
 /* per-arena status bits; each mirrors one exception site of the reference */
 #define RR_STATUS_BOT_RESOLVE_FAIL 1   /* RR_EnvBase.py:313  "UNABLE TO RESOLVE BOT/BOT COLLISIONS"   */
@@ -124,6 +124,18 @@ int rr_get_state(rr_env *env, double *robots, int32_t *robots_i, double *balls, 
 /* Poses only -- the reference's lst_starting_config format (RR_EnvBase.py:35-52,131-153) plus ball
  * velocities: robots_xyr [N,NR,3], balls_xyv [N,NB,4]; edges re-derived, history cleared. */
 int rr_set_poses(rr_env *env, const double *robots_xyr, const double *balls_xyv, void *stream);
+/* env.reset(bln_randomize_pos=False) (RR_EnvBase.py:202-216 -> _set_starting_positions :131-153): the arenas whose mask
+ * byte is non-zero (mask == NULL: all) restart at the given start configuration -- robots_xyr [N,NR,3], balls_xyv [N,NB,4]
+ * (the reference's lst_starting_config, zero ball velocities) -- with step count 0, thrust 0, no pose history; obs / obs_g
+ * (nullable) receive the first observations of the masked arenas.  The caller keeps the layout (the Python mirror retains
+ * the construction placement exactly like GameEnv.__init__ keeps self._lst_starting_positions, RR_EnvBase.py:111-116). */
+int rr_reset_to_poses(rr_env *env, const uint8_t *mask, const double *robots_xyr, const double *balls_xyv, float *obs,
+                      float *obs_g, void *stream);
+/* Episode bookkeeping for checkpoint / resume (build-side; the reference pickles the agent and never the env):
+ * ints [N,5] = episode index (keys the reset RNG), steps in the running episode, finished episodes, length of the last
+ * finished episode, fault flag; acc [N,4] = running return happy / grumpy, last finished return happy / grumpy. */
+int rr_get_episode_state(rr_env *env, int32_t *ints, double *acc, void *stream);
+int rr_set_episode_state(rr_env *env, const int32_t *ints, const double *acc, void *stream);
 
 /* ---- the reference's other mixins; SimpleDuel3's own stack is the default and is fused
  * into the step kernel, anything else is evaluated by light side kernels around it.

@@ -8,6 +8,8 @@ standins.py and writes small .npz fixtures into tests/golden/:
   traj_<preset>.npz   full-state trajectories of SimpleDuel3.step()
                       (RR_EnvBase.py:260-297) under scripted policies
   reset_<preset>.npz  layouts produced by reference reset() (RR_EnvBase.py:155-216)
+  mix_<preset>.npz    other reward / observer mixins (part "mix")
+  thrust_<preset>.npz trajectories through the continuous-thrust entry GameEnv.step (part "thrust")
 
 usage:  python oracle/refgen/gen_golden.py [G|T|all]
 One preset per process (constants are module globals in the reference), so
@@ -227,9 +229,17 @@ def run_episode(R, env, kind, NA, nsteps, rng, scramble, vmax, cnt=None):
     return out
 
 
+def reset_scratch_rect(R):
+    """The module-global scratch rect _rectBallInner (RR_TrashyPhysics.py:29-36) keeps whatever the last contact test of
+    the process left in it; episode 0 must not inherit that from the KAT / reset generators that ran before."""
+    R.tp._rectBallInner.center = (0.0, 0.0)
+    R.tp._rectBallInner.rotation = 0
+
+
 def gen_traj(R, preset):
     cnt = Counters(R)
     env = R.envs.SimpleDuel3()
+    reset_scratch_rect(R)
     NR = len(env.lstRobots)
     rng = random.Random(20201 if preset == "G" else 20202)
     if preset == "G":
@@ -271,6 +281,118 @@ def gen_traj(R, preset):
                                   inner="_rectBallInner cx,cy,rot (module-global scratch rect, RR_TrashyPhysics.py:29-36)"))
     packed["meta"] = np.array(json.dumps(meta))
     np.savez_compressed(os.path.join(GOLD, f"traj_{preset}.npz"), **packed)
+
+
+# ------------------------------------------------------------------ continuous-thrust entry (RR_EnvBase.py:260-273)
+THRUST_MENU = [-2.5, -1.5, -1.0, -0.51, -0.5, -0.49, 0.0, 0.49, 0.5, 0.51, 1.0, 1.5, 2.5]
+THRUST_SCALE = [1.0, 1.0, 1.0, 0.51, 1.49, 0.5, 1.5, 2.5]  # of a Direction's (L, R): rounds to 1,1,1,1,1,0,2,2
+DIR_LR = [(1, 1), (-1, -1), (-1, 1), (1, -1), (0, 1), (1, 0), (-1, 0), (0, -1)]  # RR_EnvBase.py:593-602
+
+
+def run_thrust_episode(R, env, NK, nsteps, rng, scramble, vmax, cnt, dtype):
+    """Like run_episode, but drives the reference through GameEnv.step (the Box-thrust entry, bypassing
+    GameEnv_Simple.step's Direction table) with flat (L, R) float pairs for the first NK robots."""
+    const = R.const
+    random.seed(rng.randint(0, 1 << 30))
+    env.reset()
+    if scramble:
+        for b in env.lstBalls:
+            b.set_velocity(rng.uniform(-vmax, vmax), rng.uniform(-vmax, vmax))
+    NR, NB = len(env.lstRobots), len(env.lstBalls)
+    S = dict(robots=np.zeros((nsteps + 1, NR, 10)), robots_i=np.zeros((nsteps + 1, NR, 3), np.int32),
+             balls=np.zeros((nsteps + 1, NB, 8)), inner=np.zeros((nsteps + 1, 3)), step=np.zeros(nsteps + 1, np.int32))
+    out = dict(thrust=np.full((nsteps, NR, 2), NAN), obs=np.full((nsteps, 11), NAN), obs_g=np.full((nsteps, 11), NAN),
+               reward=np.zeros(nsteps), reward_g=np.zeros(nsteps), done=np.zeros(nsteps, np.uint8),
+               naughty=np.zeros(nsteps, np.int32), warn=np.zeros(nsteps, np.int32))
+
+    def put(i):
+        d = dump_state(env, R)
+        for k in S:
+            S[k][i] = d[k]
+    put(0)
+    length, exc = 0, 0
+    for s in range(nsteps):
+        pairs = []
+        for i in range(NK):
+            u = rng.random()
+            if u < 0.55:  # a chasing Direction, scaled so that round() lands on 0 / 1 / 2 through the half-way cases
+                ball = env.lstBalls[i % NB]
+                a = chase_action(env.get_game_state(obj_robot=env.lstRobots[i], obj_ball=ball), rng, 0.1)
+                k = rng.choice(THRUST_SCALE)
+                pairs.append((DIR_LR[a][0] * k, DIR_LR[a][1] * k))
+            elif u < 0.9:
+                pairs.append((rng.choice(THRUST_MENU), rng.choice(THRUST_MENU)))
+            else:
+                pairs.append((rng.uniform(-2.6, 2.6), rng.uniform(-2.6, 2.6)))
+        arr = np.asarray(pairs, dtype=dtype)
+        out["thrust"][s, :NK] = arr.astype(np.float64)  # exactly the values the reference saw
+        try:
+            cnt.warns = 0
+            # the form main.py / a Box policy use: a list of per-robot (L, R) tuples (RR_EnvBase.py:269 flattens it)
+            o, r, d, info = R.base.GameEnv.step(env, [tuple(p) for p in arr])
+        except Exception as e:
+            exc = exc_code(e)
+            break
+        out["obs"][s] = o
+        if info.adblGrumpyState is not None:
+            out["obs_g"][s] = info.adblGrumpyState
+        out["reward"][s] = r
+        out["reward_g"][s] = info.dblGrumpyScore
+        out["done"][s] = d
+        nm = 0
+        for i, rb in enumerate(env.lstRobots):
+            if rb in env.set_naughty_bots:
+                nm |= 1 << i
+        out["naughty"][s] = nm
+        out["warn"][s] = cnt.warns
+        put(s + 1)
+        length = s + 1
+        if d:
+            break
+    out.update({"state_" + k: v for k, v in S.items()})
+    out["length"] = np.int32(length)
+    out["exc"] = np.int32(exc)
+    return out
+
+
+def gen_thrust(R, preset):
+    cnt = Counters(R)
+    env = R.envs.SimpleDuel3()
+    reset_scratch_rect(R)
+    NR = len(env.lstRobots)
+    rng = random.Random(31001 if preset == "G" else 31002)
+    if preset == "G":  # (robots driven, steps, scramble ball velocities, vmax, dtype the policy hands over)
+        plan = [(NR, 120, False, 0, np.float64), (NR, 120, True, 6.0, np.float32), (2, 100, True, 4.0, np.float64),
+                (1, 80, False, 0, np.float32), (NR, 120, True, 9.0, np.float64), (3, 100, True, 3.0, np.float64)]
+    else:
+        plan = [(1, 200, False, 0, np.float64), (1, 200, True, 6.0, np.float32), (1, 302, True, 3.0, np.float64),
+                (1, 200, True, 9.0, np.float64), (1, 302, False, 0, np.float32)]
+    eps = []
+    for (NK, n, scr, vmax, dt) in plan:
+        ep = run_thrust_episode(R, env, NK, n, rng, scr, vmax, cnt, dt)
+        print(preset, "thrust", NK, "len", int(ep["length"]), "exc", int(ep["exc"]), cnt.c, flush=True)
+        eps.append(ep)
+    smax = max(e["thrust"].shape[0] for e in eps)
+    packed = {}
+    for k in eps[0]:
+        arrs = [e[k] for e in eps]
+        if arrs[0].ndim == 0:
+            packed[k] = np.stack(arrs)
+            continue
+        tgt = smax + 1 if k.startswith("state_") else smax
+        pad = []
+        for a in arrs:
+            p = np.full((tgt,) + a.shape[1:], NAN, a.dtype) if k == "thrust" else np.zeros((tgt,) + a.shape[1:], a.dtype)
+            p[:a.shape[0]] = a
+            pad.append(p)
+        packed[k] = np.stack(pad)
+    rounded = sorted({float(v) for v in np.unique(np.rint(packed["thrust"][~np.isnan(packed["thrust"])]))})
+    meta = dict(META, preset=preset, plan=[[a, b, c, d, np.dtype(e).name] for (a, b, c, d, e) in plan], coverage=cnt.c,
+                entry="GameEnv.step(env, [(L, R), ...]) -- RR_EnvBase.py:260-273, Robot.set_thrust RR_Robot.py:100-102",
+                thrust_menu=THRUST_MENU, thrust_scales=THRUST_SCALE, rounded_values_seen=rounded,
+                note="thrust[e, s, i] = the (L, R) floats robot i was given (NaN: robot got none and keeps its thrust)")
+    packed["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(GOLD, f"thrust_{preset}.npz"), **packed)
 
 
 # ------------------------------------------------------------------ KATs
@@ -576,6 +698,8 @@ def main():
         gen_traj(R, which)
     if "mix" in parts:
         gen_mix(R, which)
+    if "thrust" in parts:
+        gen_thrust(R, which)
 
 
 if __name__ == "__main__":

@@ -47,6 +47,9 @@ SYMBOLS = {
     "rr_set_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "rr_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "rr_set_poses": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "rr_reset_to_poses": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rr_get_episode_state": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "rr_set_episode_state": (C.c_int, [_vp, _vp, _vp, _vp]),
     "rr_episode_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "rr_state_bytes_per_env": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "rr_lanes_per_env": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
@@ -60,14 +63,18 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        # not a fallback: the only thing ever loaded is the HIP library, built here if the in-tree .so is absent
+    from . import build as _build
+    stale = "RR_LIB_PATH" not in os.environ and os.path.exists(LIB_PATH) and _build.sources_present() and _build.is_stale()
+    if not os.path.exists(LIB_PATH) or stale:
+        # not a fallback: the only thing ever loaded is the HIP library, (re)built here if the in-tree .so is absent or
+        # older than its sources (an edited rr_sim.hpp must never be tested against yesterday's kernels)
         try:
             if "RR_LIB_PATH" in os.environ:
                 raise RuntimeError("RR_LIB_PATH points to a missing file")
-            from .build import build_hip_library
-            build_hip_library(verbose=True)
+            _build.build_hip_library(verbose=True)
         except Exception as exc:
+            if stale:
+                raise ImportError(f"{LIB_PATH} is older than its sources and could not be rebuilt ({exc})") from exc
             raise ImportError(
                 f"{LIB_PATH} is missing and could not be built ({exc}): run `python -m roborugby_amd.build`. "
                 "roborugby_amd has no CPU fallback.") from exc

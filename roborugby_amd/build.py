@@ -1,4 +1,9 @@
-"""Builds the HIP shared library in-tree (roborugby_amd/libroborugby_amd.so) for gfx950."""
+"""Builds the HIP shared library in-tree (roborugby_amd/libroborugby_amd.so) for gfx950.
+
+Staleness is decided by CONTENT, not mtime: the build records the sha256 of every source it compiled (and of the compiler
+flags) next to the library; a library whose recorded hash differs from the sources' is rebuilt before anything loads it.
+(A snapshot copied to another box keeps contents, not necessarily timestamps.)"""
+import hashlib
 import os
 import shutil
 import subprocess
@@ -8,6 +13,7 @@ SRC = os.path.join(HERE, "csrc", "rr_kernels.hip")
 DEPS = [SRC, os.path.join(HERE, "csrc", "rr_sim.hpp"), os.path.join(HERE, "csrc", "rr_extras.hpp"),
         os.path.join(os.path.dirname(HERE), "include", "roborugby_amd.h")]
 LIB = os.path.join(HERE, "libroborugby_amd.so")
+STAMP = LIB + ".srchash"
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 
@@ -18,18 +24,38 @@ def find_hipcc():
     raise RuntimeError("hipcc not found: the MI355X library cannot be built here")
 
 
+def sources_present():
+    return all(os.path.exists(d) for d in DEPS)
+
+
+def source_hash():
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for d in DEPS:
+        with open(d, "rb") as f:
+            h.update(os.path.basename(d).encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def is_stale():
-    return not os.path.exists(LIB) or any(os.path.getmtime(LIB) < os.path.getmtime(d) for d in DEPS)
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
+        return True
+    with open(STAMP) as f:
+        return f.read().strip() != source_hash()
 
 
 def build_hip_library(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 ... -> libroborugby_amd.so (cross-compiles without a GPU)."""
     if not force and not is_stale():
         return LIB
-    cmd = [find_hipcc()] + HIPCC_FLAGS + ["-o", LIB, SRC]
+    digest = source_hash()
+    tmp = LIB + f".tmp{os.getpid()}"
+    cmd = [find_hipcc()] + HIPCC_FLAGS + ["-o", tmp, SRC]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)  # atomic: a concurrent loader sees the old or the new library, never half of one
+    with open(STAMP, "w") as f:
+        f.write(digest + "\n")
     return LIB
 
 

@@ -54,7 +54,7 @@ template <class C> RR_HD void extras_begin(const Rec<C> &q, typename C::Real *xs
     for (int r = 0; r < C::NR; r++) { // FloatRect.copy(): new rect (0,20,0,40) -> center setter -> rotation setter
         xs[3 * r + 0] = (R)10 + (q.rcx(r) - (R)10);
         xs[3 * r + 1] = (R)20 + (q.rcy(r) - (R)20);
-        xs[3 * r + 2] = py_mod<R>(q.rrot(r) + (R)720, (R)360);
+        xs[3 * r + 2] = norm360<R>(q.rrot(r));
     }
     R s = (R)0;
     V2<R> o = { (R)0, (R)0 };
@@ -68,9 +68,9 @@ template <class C> RR_HD void extras_begin(const Rec<C> &q, typename C::Real *xs
 // ---- on_step_end: the keeper program in execution order
 template <class C, typename O>
 RR_HD void extras_end(const Rec<C> &q, const SimParams<typename C::Real> &sp, const typename C::Real *xs, const Program &pg,
-                      uint32_t naughty, O *reward, O *reward_g, int32_t *status) {
+                      uint32_t naughty, O *reward, O *reward_g, int32_t *status, typename C::Real &rh, typename C::Real &rg) {
     using R = typename C::Real;
-    R rh = (R)0, rg = (R)0;
+    rh = (R)0; rg = (R)0;
     int st = 0;
     for (int k = 0; k < pg.n; k++) {
         switch (pg.id[k]) {

@@ -262,15 +262,18 @@ __global__ void k_get_state(const typename C::Real *recs, const int32_t *irecs, 
         for (int f = 0; f < 8; f++) balls[((size_t)a * NB + b) * 8 + f] = (double)rec[10 * NR + f * NB + b];
     step[a] = irec[3 * NR + 0];
 }
-template <class C>
+// rr_set_poses, and env.reset(bln_randomize_pos=False) = _set_starting_positions (RR_EnvBase.py:131-153,202-216) through
+// rr_reset_to_poses: masked arenas only, first observations out
+template <class C, typename O>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_set_poses(SimParams<typename C::Real> sp, typename C::Real *recs,
                                                                    int32_t *irecs, int n, const double *rxyr,
-                                                                   const double *bxyv) {
+                                                                   const double *bxyv, const uint8_t *mask, O *obs, O *obs_g) {
     using R = typename C::Real;
     __shared__ Arena<C> lds[arenas_per_block<C>()];
     const int wave = threadIdx.x / C::VW, lane = threadIdx.x & (C::VW - 1);
     const int arena = blockIdx.x * arenas_per_block<C>() + wave;
     if (arena >= n) return;
+    if (mask && !mask[arena]) return; // uniform per virtual wave
     Arena<C> &A = lds[wave];
     R *rec = recs + (size_t)arena * Arena<C>::P_STRIDE;
     int32_t *irec = irecs + (size_t)arena * Arena<C>::I_STRIDE;
@@ -284,7 +287,26 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_set_poses(SimParams<ty
         ball_set_clean_lane(A, lane, (R)q[0], (R)q[1], (R)q[2], (R)q[3]);
     }
     if (lane == 0) { A.i.step = 0; A.i.ep_len = 0; A.i.fault = 0; A.p.acc[0] = (R)0; A.p.acc[1] = (R)0; }
+    RR_SYNC();
+    if (obs || obs_g) {
+        int st = 0;
+        derive(A, sp);
+        if (obs) observe<C, O>(A, sp, 1, -1, -1, obs + (size_t)arena * 11, st);
+        if (obs_g && !observe<C, O>(A, sp, -1, -1, -1, obs_g + (size_t)arena * 11, st))
+            for (int k = lane; k < 11; k += C::VW) obs_g[(size_t)arena * 11 + k] = (O)NAN;
+    }
     store_record(A, rec, irec);
+}
+// episode bookkeeping <-> caller (checkpoint / resume): ints [N,5] = episode, ep_len, ep_count, last_len, fault; acc [N,4]
+template <class C>
+__global__ void k_episode_state(typename C::Real *recs, int32_t *irecs, int n, int32_t *ints, double *acc, int set) {
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    typename C::Real *rec = recs + (size_t)a * Arena<C>::P_STRIDE;
+    int32_t *irec = irecs + (size_t)a * Arena<C>::I_STRIDE;
+    constexpr int ACC = 10 * C::NR + 8 * C::NB, I0 = 3 * C::NR + 1; // after mc/thl/thr and step
+    for (int k = 0; k < 5; k++) { if (set) irec[I0 + k] = ints[(size_t)a * 5 + k]; else ints[(size_t)a * 5 + k] = irec[I0 + k]; }
+    for (int k = 0; k < 4; k++) { if (set) rec[ACC + k] = (typename C::Real)acc[(size_t)a * 4 + k]; else acc[(size_t)a * 4 + k] = (double)rec[ACC + k]; }
 }
 template <class C>
 __global__ void k_episode_stats(const typename C::Real *recs, const int32_t *irecs, int n, float *lr, float *lrg,
@@ -308,16 +330,26 @@ __global__ void k_extras_begin(const typename C::Real *recs, int n, typename C::
     Rec<C> q = { recs + (size_t)a * Arena<C>::P_STRIDE };
     extras_begin<C>(q, xs + (size_t)a * xs_stride<C>());
 }
+// After k_step, when a non-default keeper program and / or prior-step tracking is on: the program's rewards replace the
+// fused SimpleDuel3 ones AND feed the episode-return accumulators (k_step leaves them alone then: sp.acc_external), and an
+// arena that k_step re-placed (auto-reset) gets its on_step_begin copies re-seeded from the new poses, like rr_reset does.
 template <class C, typename O>
-__global__ void k_extras_end(SimParams<typename C::Real> sp, const typename C::Real *recs, int n, const typename C::Real *xs,
-                             Program pg, O *reward, O *reward_g, int32_t *status) {
+__global__ void k_extras_end(SimParams<typename C::Real> sp, typename C::Real *recs, int n, typename C::Real *xs,
+                             Program pg, int rewrite, O *reward, O *reward_g, int32_t *status, const uint8_t *done) {
+    using R = typename C::Real;
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
     const int32_t st = status[a];
-    if (st & (ST_WAS_RESET | ST_STEP_AFTER_DONE)) return; // nothing was stepped: the reward stays 0
-    Rec<C> q = { recs + (size_t)a * Arena<C>::P_STRIDE };
+    R *rec = recs + (size_t)a * Arena<C>::P_STRIDE;
+    Rec<C> q = { rec };
+    if (st & ST_WAS_RESET) { extras_begin<C>(q, xs + (size_t)a * xs_stride<C>()); return; } // new episode: no prior step yet
+    if (!rewrite || (st & ST_STEP_AFTER_DONE)) return; // nothing was stepped: the reward stays 0
+    R rh, rg;
     extras_end<C, O>(q, sp, xs + (size_t)a * xs_stride<C>(), pg, (uint32_t)st >> 16, reward + a, reward_g ? reward_g + a : nullptr,
-                     status + a);
+                     status + a, rh, rg);
+    constexpr int ACC = 10 * C::NR + 8 * C::NB; // running return happy/grumpy, last finished return happy/grumpy
+    rec[ACC + 0] += rh; rec[ACC + 1] += rg;
+    if (done[a]) { rec[ACC + 2] = rec[ACC + 0]; rec[ACC + 3] = rec[ACC + 1]; }
 }
 template <class C, typename O>
 __global__ void k_observe_kind(SimParams<typename C::Real> sp, const typename C::Real *recs, int n, int kind, int team, int ridx,
@@ -382,6 +414,7 @@ template <typename R> static void fill_params(SimParams<R> &sp, const rr_config 
     sp.inner_cdist = (R)std::pow(hr * hr + hr * hr, .5);
     sp.game_len = c.game_len_steps; sp.game_mode = c.game_mode; sp.time_limit = c.time_limit; sp.auto_reset = c.auto_reset;
     sp.reset_on_fault = c.reset_on_fault;
+    sp.acc_external = 0;
     { const char *nm = getenv("RR_NO_MEMO"); sp.memo = (nm && atoi(nm)) ? 0 : 1; } // fixed-point check of the sub-step loop (exact; the switch is for A/B runs)
     sp.seed = c.seed; sp.arena_offset = c.arena_offset;
 }
@@ -429,7 +462,7 @@ int rr_create(const rr_config *cfg, rr_env **out) {
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev) return fail(-1, "rr_create: no such HIP device");
-    HIP_TRY(hipSetDevice(cfg->device));
+    DeviceGuard guard(cfg->device); // the caller's current device is left as found (like every other entry point)
     rr_env *e = new (std::nothrow) rr_env();
     if (!e) return fail(-3, "rr_create: out of host memory");
     e->cfg = *cfg;
@@ -499,7 +532,7 @@ int rr_create(const rr_config *cfg, rr_env **out) {
 
 int rr_destroy(rr_env *e) {
     if (!e) return 0;
-    (void)hipSetDevice(e->cfg.device);
+    DeviceGuard guard(e->cfg.device);
     (void)hipFree(e->recs);
     (void)hipFree(e->irecs);
     if (e->xs) (void)hipFree(e->xs);
@@ -544,7 +577,7 @@ static int step_impl(rr_env *e, const int32_t *actions, const float *thrust, int
     const int n = e->cfg.num_envs;
     DeviceGuard guard(e->cfg.device);
     hipStream_t s = (hipStream_t)stream;
-    if (e->custom_prog && !status) status = e->status_buf; // the side kernels need the NaughtyBots bits
+    if ((e->custom_prog || e->track_prior) && !status) status = e->status_buf; // the side kernels need the NaughtyBots / WAS_RESET bits
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
         if constexpr (std::is_same<O, double>::value && !std::is_same<RR, double>::value) {
@@ -563,9 +596,10 @@ static int step_impl(rr_env *e, const int32_t *actions, const float *thrust, int
             else
                 return fail(-1, "rr_rollout: built for float outputs and the default lane widths (RR_VW unset) only");
             if (e->order) hipLaunchKernelGGL(k_order, dim3(1), dim3(ORDER_THREADS), 0, s, (const uint32_t *)e->cost, e->order, e->ngroups);
-            if (e->custom_prog)
+            if (e->custom_prog || e->track_prior)
                 hipLaunchKernelGGL((k_extras_end<CC, O>), dim3((n + 127) / 128), dim3(128), 0, s, params_of<RR>(e),
-                                   (const RR *)e->recs, n, (const RR *)e->xs, e->prog, reward, reward_g, status);
+                                   (RR *)e->recs, n, (RR *)e->xs, e->prog, e->custom_prog ? 1 : 0, reward, reward_g, status,
+                                   (const uint8_t *)done);
             return 0;
         }
     });
@@ -616,6 +650,7 @@ int rr_set_reward_program(rr_env *e, const int32_t *ids, int32_t n) {
     e->prog.n = n;
     for (int i = 0; i < n; i++) e->prog.id[i] = ids[i];
     e->custom_prog = !(n == 3 && ids[0] == KEEPER_NAUGHTY && ids[1] == KEEPER_CHASE && ids[2] == KEEPER_PUSHPOS);
+    e->spd.acc_external = e->spf.acc_external = e->custom_prog ? 1 : 0; // k_extras_end keeps the episode returns then
     if (e->custom_prog) { // allocated here, never inside rr_step (keeps the step launch-only)
         if (int rc = ensure_snapshot_buffer(e)) return rc;
         if (!e->status_buf) HIP_TRY(hipMalloc((void **)&e->status_buf, sizeof(int32_t) * (size_t)e->cfg.num_envs));
@@ -629,6 +664,7 @@ int rr_track_prior_step(rr_env *e, int32_t on, void *stream) {
     e->track_prior = on != 0;
     if (!e->track_prior) return 0;
     if (int rc = ensure_snapshot_buffer(e)) return rc;
+    if (!e->status_buf) HIP_TRY(hipMalloc((void **)&e->status_buf, sizeof(int32_t) * (size_t)e->cfg.num_envs));
     // until the first step the prior-step copies are copies of the current state (the reference's hold the stale
     // pre-placement pose there: Robot.on_reset / Ball.on_reset copy BEFORE _set_random_positions moves the sprites)
     const int n = e->cfg.num_envs;
@@ -751,19 +787,45 @@ int rr_get_state(rr_env *e, double *robots, int32_t *ri, double *balls, int32_t 
     HIP_TRY(hipGetLastError());
     return 0;
 }
-int rr_set_poses(rr_env *e, const double *rxyr, const double *bxyv, void *stream) {
-    if (!e || !rxyr || !bxyv) return fail(-1, "rr_set_poses: null argument");
+static int set_poses_impl(rr_env *e, const uint8_t *mask, const double *rxyr, const double *bxyv, float *obs, float *obs_g, void *stream) {
     const int n = e->cfg.num_envs;
     DeviceGuard guard(e->cfg.device);
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
-        hipLaunchKernelGGL((k_set_poses<CC>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
-                           (RR *)e->recs, e->irecs, n, rxyr, bxyv);
+        hipLaunchKernelGGL((k_set_poses<CC, float>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
+                           (RR *)e->recs, e->irecs, n, rxyr, bxyv, mask, obs, obs_g);
+        if (e->track_prior && e->xs) // like rr_reset: a re-placed arena has no prior step yet
+            hipLaunchKernelGGL((k_extras_begin<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const RR *)e->recs, n, (RR *)e->xs, mask);
         return 0;
     });
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
+}
+int rr_set_poses(rr_env *e, const double *rxyr, const double *bxyv, void *stream) {
+    if (!e || !rxyr || !bxyv) return fail(-1, "rr_set_poses: null argument");
+    return set_poses_impl(e, nullptr, rxyr, bxyv, nullptr, nullptr, stream);
+}
+int rr_reset_to_poses(rr_env *e, const uint8_t *mask, const double *rxyr, const double *bxyv, float *obs, float *obs_g, void *stream) {
+    if (!e || !rxyr || !bxyv) return fail(-1, "rr_reset_to_poses: null argument");
+    return set_poses_impl(e, mask, rxyr, bxyv, obs, obs_g, stream);
+}
+static int episode_state_impl(rr_env *e, int32_t *ints, double *acc, int set, void *stream) {
+    if (!e || !ints || !acc) return fail(-1, "rr_get/set_episode_state: null argument");
+    const int n = e->cfg.num_envs;
+    DeviceGuard guard(e->cfg.device);
+    int rc = dispatch(e, [&](auto c) {
+        using CC = decltype(c); using RR = typename CC::Real;
+        hipLaunchKernelGGL((k_episode_state<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (RR *)e->recs, e->irecs, n, ints, acc, set);
+        return 0;
+    });
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int rr_get_episode_state(rr_env *e, int32_t *ints, double *acc, void *stream) { return episode_state_impl(e, ints, acc, 0, stream); }
+int rr_set_episode_state(rr_env *e, const int32_t *ints, const double *acc, void *stream) {
+    return episode_state_impl(e, const_cast<int32_t *>(ints), const_cast<double *>(acc), 1, stream);
 }
 int rr_episode_stats(rr_env *e, float *lr, float *lrg, int32_t *ll, int32_t *cnt, void *stream) {
     if (!e) return fail(-1, "rr_episode_stats: null handle");

@@ -186,6 +186,19 @@ template <typename R> RR_HD bool is_nan(R x) { return x != x; }
 template <typename R> RR_HD R pi_() { return (R)3.14159265358979323846; }
 template <typename R> RR_HD R radians(R x) { return x * (pi_<R>() / (R)180.0); } // math.radians
 template <typename R> RR_HD R degrees(R x) { return x * ((R)180.0 / pi_<R>()); } // math.degrees
+// sin & cos of an angle given in degrees, as the reference takes them: math.sin(math.radians(deg)).  fp64: exactly that.
+// fp32 fast mode: the angles here reach 810 degrees = 14 rad, where one fp32 ulp of the ARGUMENT is 1e-6 rad -- 1.5e-5 px on
+// the 16-px pivot arm, every sub-step.  Bringing the angle into [-180, 180] first is exact in fp32 (Sterbenz) and shrinks
+// that fourfold; the function value is the same.
+template <typename R> RR_HD void sincos_deg(R deg, R &s, R &c) { m_sincos(radians<R>(deg), s, c); }
+template <> RR_HD void sincos_deg<float>(float deg, float &s, float &c) {
+    float d = deg;
+    d = d >= 360.0f ? d - 360.0f : d;
+    d = d >= 360.0f ? d - 360.0f : d;
+    d = d > 180.0f ? d - 360.0f : d;
+    d = d < -180.0f ? d + 360.0f : d;
+    m_sincos(radians<float>(d), s, c);
+}
 template <typename R> RR_HD R py_mod(R a, R b) {                                 // Python float %
     R m = m_fmod(a, b);
     if (m != (R)0) {
@@ -218,6 +231,15 @@ template <> RR_HD double py_mod<double>(double a, double b) {
         r = (r < 0.0) ? r + 360.0 : r;
     }
     return r == 0.0 ? 0.0 : r;
+}
+// `(x + 720) % 360`, the reference's angle normalisation (MyUtils.py:279, :98).  fp64: exactly that, rounding of x + 720
+// included (parity).  fp32 fast mode: the sum would drop the bits of x below ulp(1024) = 6e-5 degrees on EVERY turn, and 16 px
+// of pivot arm turn that into ~1e-4 px per step; the float instance evaluates the same expression in fp64 and rounds once, so
+// an angle already in [0, 360) comes back unchanged, as it does in exact arithmetic.
+template <typename R> RR_HD R norm360(R x) { return py_mod<R>(x + (R)720, (R)360); }
+template <> RR_HD float norm360<float>(float x) {
+    const float r = (float)py_mod<double>((double)x + 720.0, 360.0);
+    return r >= 360.0f ? 0.0f : r; // 359.99999999 rounds up to the float 360 = 0 on the circle
 }
 template <typename R> RR_HD R py_max(R a, R b) { return (b > a) ? b : a; } // first maximal wins
 template <typename R> RR_HD R py_min(R a, R b) { return (b < a) ? b : a; }
@@ -280,7 +302,7 @@ template <typename R> RR_HD R angle_degrees(V2<R> a, V2<R> b, int &st) {
     R dy = b.y - a.y, dx = b.x - a.x;
     R ang = m_atan(div0<R>(dy, dx, st));
     if (dx < (R)0) ang += pi_<R>();
-    return py_mod<R>(degrees<R>((R)2 * pi_<R>() - ang) + (R)720, (R)360);
+    return norm360<R>(degrees<R>((R)2 * pi_<R>() - ang));
 }
 
 // ------------------------------------------------------------------------------------------------ config
@@ -303,6 +325,7 @@ template <typename R> struct SimParams {
     R inner_h, inner_cdist;      // half side / corner dist of _rectBallInner (RR_TrashyPhysics.py:29-35)
     int32_t game_len, game_mode, time_limit, auto_reset, reset_on_fault;
     int32_t memo;                // stop the sub-step loop at a bitwise fixed point (exact shortcut, see step_arena)
+    int32_t acc_external;        // a non-default keeper program owns the episode-return accumulators (k_extras_end), not step_arena
     uint64_t seed, arena_offset;
 };
 
@@ -413,7 +436,7 @@ template <typename R> RR_HD void corners_from_sc(R rot, R s, R c, R hw, R hh, R 
 }
 template <typename R> RR_HD void corners_for(R rot, R hw, R hh, R cdist, R *rel) {
     R c, s;
-    m_sincos(radians<R>((R)360 - rot), s, c);
+    sincos_deg<R>((R)360 - rot, s, c);
     corners_from_sc<R>(rot, s, c, hw, hh, cdist, rel);
 }
 template <typename R> RR_HD void fr_edges_from_rel(FR<R> &f) { // MyUtils.py:318-322
@@ -428,7 +451,7 @@ template <typename R> RR_HD void fr_edges_from_rel(FR<R> &f) { // MyUtils.py:318
     f.l = mnx + f.cx; f.r = mxx + f.cx; f.t = mny + f.cy; f.b = mxy + f.cy;
 }
 template <typename R> RR_HD void fr_set_rot(FR<R> &f, R nr, R cdist) { // robot rect: 20 x 40
-    nr = py_mod<R>(nr + (R)720, (R)360);
+    nr = norm360<R>(nr);
     if (nr == f.rot) return;
     f.rot = nr;
     corners_for<R>(nr, (R)10, (R)20, cdist, f.rel);
@@ -495,7 +518,7 @@ template <class C> RR_HD MovePlan<typename C::Real> robot_move_plan(const Arena<
     m.spin = !m.lin && (L + Rt == 0);
     const R w = m.lin ? (R)0 : m.spin ? (Rt > 0 ? (R)1.2 : (R)-1.2) : ((Rt > 0 || L < 0) ? (R).6 : (R)-.6);
     m.off = (Rt != 0) ? (R)90 : (R)-90; // pivot = left track (rot+90) when the right one drives
-    m.nrot = m.lin ? rot : py_mod<R>((rot + w) + (R)720, (R)360);
+    m.nrot = m.lin ? rot : norm360<R>(rot + w);
     m.a1 = m.lin ? rot : rot + m.off;   // heading (linear) / direction of the pivot (track) centre
     m.a2 = (R)360 - m.nrot;             // rotation setter
     m.a3 = m.nrot + -m.off;             // robot centre as seen from the pivot after the turn
@@ -535,7 +558,7 @@ RR_HD void robot_move_finish(Arena<C> &A, const SimParams<typename C::Real> &sp,
             // normalised value is almost always rot_prior itself (it came out of this very normalisation one move ago),
             // and then the corners the setter would rebuild are the ones still sitting in LDS: A.rel is always
             // corners_for(rrot) and store_robot has not run yet.  Only a value the +720 really perturbs pays the trig.
-            const R nr = py_mod<R>(rot_prior + (R)720, (R)360);
+            const R nr = norm360<R>(rot_prior);
             if (nr != f.rot) {
                 f.rot = nr;
                 if (nr == rot_prior) {
@@ -559,9 +582,9 @@ template <class C> RR_HD void robot_move_lane(Arena<C> &A, const SimParams<typen
     A.i.mc[r] += 1;
     if (m.idle) { A.wm[r] = 0; return; }
     R s1, c1, s2, c2, s3, c3;
-    m_sincos(radians<R>(m.a1), s1, c1);
-    m_sincos(radians<R>(m.a2), s2, c2);
-    m_sincos(radians<R>(m.a3), s3, c3);
+    sincos_deg<R>(m.a1, s1, c1);
+    sincos_deg<R>(m.a2, s2, c2);
+    sincos_deg<R>(m.a3, s3, c3);
     R tlx, tly, trx, try_;
     corner_from_sc<R>(m.nrot, s2, c2, (R)-10, (R)-20, sp.rob_cdist, tlx, tly);
     corner_from_sc<R>(m.nrot, s2, c2, (R)10, (R)-20, sp.rob_cdist, trx, try_);
@@ -583,7 +606,7 @@ template <class C> RR_HD void refresh_inner_lane(Arena<C> &A, const SimParams<ty
     R rot = A.p.rrot[r];
     if (A.irot[r] == rot) return;
     A.irot[r] = rot;
-    corners_for<R>(py_mod<R>(rot + (R)45 + (R)720, (R)360), sp.inner_h, sp.inner_h, sp.inner_cdist, A.u.irel[r]);
+    corners_for<R>(norm360<R>(rot + (R)45), sp.inner_h, sp.inner_h, sp.inner_cdist, A.u.irel[r]);
 }
 
 // side slope/intercept cache: one lane per (robot, side), rebuilt on demand after robot poses changed
@@ -759,7 +782,7 @@ template <class C, bool CACHED> RR_HD uint32_t detect_ball_robot(Arena<C> &A, co
                     ox = A.u.irel[r][2 * d]; oy = A.u.irel[r][2 * d + 1];
                 } else {
                     R iq[8];
-                    corners_for<R>(py_mod<R>(A.p.rrot[r] + (R)45 + (R)720, (R)360), sp.inner_h, sp.inner_h, sp.inner_cdist, iq);
+                    corners_for<R>(norm360<R>(A.p.rrot[r] + (R)45), sp.inner_h, sp.inner_h, sp.inner_cdist, iq);
                     ox = d == 0 ? iq[0] : iq[2]; oy = d == 0 ? iq[1] : iq[3];
                 }
                 Seg<R> dia = { { bc.x + ox, bc.y + oy }, { bc.x + -ox, bc.y + -oy } };
@@ -867,7 +890,7 @@ RR_HD PrevPose<typename C::Real> robot_prev_frame(const Arena<C> &A, const SimPa
     if (bots_moved & (1u << r)) { q.x = ccx + (A.ax[r] - ccx); q.y = ccy + (A.ay[r] - ccy); rot = A.arot[r]; }
     else if (!is_nan(A.p.px[r])) { q.x = ccx + (A.p.px[r] - ccx); q.y = ccy + (A.p.py[r] - ccy); rot = A.p.prot[r]; }
     else { q.x = ccx; q.y = ccy; rot = A.p.rrot[r]; }
-    const R nr = py_mod<R>(rot + (R)720, (R)360);
+    const R nr = norm360<R>(rot);
     if (nr == A.p.rrot[r]) {
         // same rotation value as the live rect (a robot driving straight, or one that has not turned since): the setter
         // returns early and the copy keeps the live corners -- which ARE corners_for(rrot): every writer of A.rel builds
@@ -1306,7 +1329,7 @@ RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, co
             R s_ = (R)0, c_ = (R)1;
             if (robot_lane) {
                 const MovePlan<R> m = robot_move_plan(A, r);
-                m_sincos(radians<R>(part == 0 ? m.a1 : m.a2), s_, c_);
+                sincos_deg<R>(part == 0 ? m.a1 : m.a2, s_, c_);
                 RR_LV(mp, l) = m;
             }
             RR_LV(sv, l) = s_; RR_LV(cv, l) = c_;
@@ -1359,7 +1382,7 @@ RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, co
                 A.i.mc[r] += 1;
                 if (!m.idle) {
                     R s3, c3;
-                    m_sincos(radians<R>(m.a3), s3, c3);
+                    sincos_deg<R>(m.a3, s3, c3);
                     robot_move_finish(A, sp, r, m, RR_LV(sv, l), RR_LV(cv, l), s3, c3, RR_LV(qx, l), RR_LV(qy, l), trx, try_);
                 } else {
                     A.wm[r] = 0;
@@ -1753,7 +1776,7 @@ template <class C> RR_HD void robot_set_clean_lane(Arena<C> &A, const SimParams<
                                                    typename C::Real x, typename C::Real y, typename C::Real rot) {
     using R = typename C::Real;
     FR<R> f;
-    f.cx = x; f.cy = y; f.rot = py_mod<R>(rot + (R)720, (R)360);
+    f.cx = x; f.cy = y; f.rot = norm360<R>(rot);
     corners_for<R>(f.rot, (R)10, (R)20, sp.rob_cdist, f.rel);
     fr_edges_from_rel<R>(f);
     store_robot(A, r, f);
@@ -2125,8 +2148,12 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
         if (o.reward_g()) *o.reward_g() = (O)rew_g;
         if (o.status()) *o.status() = st | (int)(naughty << 16); // bits 16..: robots NaughtyBots flagged this step
         // episode bookkeeping for logging (the caller sums `score` the same way, Training_DQN_pytorch.py:345-346)
-        A.p.acc[0] += rew_h; A.p.acc[1] += rew_g; A.i.ep_len += 1;
-        if (done) { A.p.acc[2] = A.p.acc[0]; A.p.acc[3] = A.p.acc[1]; A.i.last_len = A.i.ep_len; A.i.ep_count += 1; }
+        A.i.ep_len += 1;
+        if (!sp.acc_external) { A.p.acc[0] += rew_h; A.p.acc[1] += rew_g; }
+        if (done) {
+            if (!sp.acc_external) { A.p.acc[2] = A.p.acc[0]; A.p.acc[3] = A.p.acc[1]; }
+            A.i.last_len = A.i.ep_len; A.i.ep_count += 1;
+        }
         if (faulted) A.i.fault = 1;
     }
     RR_SYNC();

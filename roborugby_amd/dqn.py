@@ -1,17 +1,29 @@
 """Batched DQN trainer: the vectorised counterpart of the reference's Training_DQN_pytorch.py (BASELINE.json config 5).
 
 Same agent as the reference (`DeepQNetwork` Training_DQN_pytorch.py:25-67: Linear 11->256->256->8 with ReLU, Adam
-lr 5e-4, MSE; `DQNAgent` :70-197: gamma .99, epsilon 1.0 decayed by x0.999997 per learn() down to 0.2, target
-network copied every `target_update_freq` stored transitions, uniform replay sampled WITHOUT replacement, batch =
-max_episode_steps*8+100) and the same call pattern as its main loop (:317-377: choose_action -> env.step ->
-store_transition (+ the grumpy team's transition when it has robots) -> learn() once per step), but every tensor --
-observations, replay memory, networks -- stays on the MI355X and one call handles all N arenas.
+lr 5e-4, MSE; `DQNAgent` :70-197: gamma .99, epsilon-greedy, target network, uniform replay) and the same call pattern as
+its main loop (:317-377: choose_action -> env.step -> store_transition (+ the grumpy team's transition when it has robots)
+-> learn()), but every tensor -- observations, replay memory, networks -- stays on the MI355X and one call handles all N
+arenas.
 
-    python -m roborugby_amd.dqn --num-envs 65536 --steps 300
+What "one learn() per env.step" becomes when a step delivers N transitions (the reference: N = 1).  Every schedule the
+reference ties to its step counter is kept PER TRANSITION, so it means the same at any N:
+  * epsilon:  eps <- max(eps * eps_dec ** n_new, eps_end) for the n_new transitions stored since the last update
+              (reference: one factor eps_dec per learn() = per transition, :186-191; 1.0 -> 0.2 after 5.4e5 transitions);
+  * target:   Q_target <- Q_eval whenever `target_update_freq` more transitions have been stored (reference :187; in the
+              reference that is also 100,000 gradient updates -- its target network is nearly frozen -- so train() scales
+              it with the batch: max(100,000, target_sync_vector_steps * N) transitions);
+  * replay:   `replay_vector_steps` vector steps deep (at least the reference's 500,000 transitions);
+  * update-to-data: the reference draws 2,500 samples per transition, which at 65,536 transitions per step would be
+              1.6e8 samples per step.  Here `updates_per_step` (k) gradient steps of `batch_size` (B) samples follow every
+              vector step: k * B / N samples per transition (defaults k = 4, B = 32,768: 2 per transition at 65,536 arenas).
+
+    python -m roborugby_amd.dqn --num-envs 65536 --steps 3000 --eval-every 300 --out profiles/r02/dqn_T_65536.json
 """
 import argparse
 import copy
 import json
+import math
 import os
 import time
 
@@ -39,6 +51,7 @@ class DeepQNetwork(nn.Module):
 
 class BatchedDQNAgent:
     """DQNAgent (Training_DQN_pytorch.py:70-197) with [N]-batched choose_action/store_transition and device replay."""
+    PERMUTE_LIMIT = 1 << 20  # sample without replacement (reference: np.random.choice(replace=False)) while a permutation is cheap
 
     def __init__(self, gamma=.99, epsilon=1.0, lr=.0005, input_dims=11, batch_size=2500, n_actions=8,
                  max_mem_size=500000, eps_end=0.2, eps_dec=.999997, fc1_dims=256, fc2_dims=256,
@@ -47,8 +60,11 @@ class BatchedDQNAgent:
         self.n_actions, self.mem_size, self.batch_size = n_actions, int(max_mem_size), int(batch_size)
         self.target_update_freq = int(target_update_freq)
         self.device = torch.device(device)
-        self.mem_cntr = 0
+        self.mem_cntr = 0            # transitions stored so far (the reference's mem_cntr)
+        self._eps_cntr = 0           # ... of which the epsilon schedule has already been charged
         self._next_target_sync = self.target_update_freq
+        self.target_syncs = 0
+        self.updates = 0
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(seed)
         torch.manual_seed(seed)
@@ -68,9 +84,11 @@ class BatchedDQNAgent:
     @torch.no_grad()
     def choose_action(self, observation, epsilon_override=None):
         """[N,11] -> int32 [N]: epsilon-greedy per arena (Training_DQN_pytorch.py:138-149)."""
-        eps = epsilon_override if epsilon_override else self.epsilon
+        eps = self.epsilon if epsilon_override is None else epsilon_override
         n = observation.shape[0]
         greedy = self.Q_eval(observation).argmax(dim=1)
+        if eps <= 0:
+            return greedy.to(torch.int32)
         rand = torch.randint(0, self.n_actions, (n,), generator=self.gen, device=self.device)
         explore = torch.rand(n, generator=self.gen, device=self.device) <= eps
         return torch.where(explore, rand, greedy).to(torch.int32)
@@ -93,10 +111,16 @@ class BatchedDQNAgent:
         self.terminal_memory[pos] = done.bool()
         self.mem_cntr += n
 
+    def _sample(self, max_mem):
+        if max_mem <= self.PERMUTE_LIMIT:
+            return torch.randperm(max_mem, generator=self.gen, device=self.device)[:self.batch_size]  # replace=False
+        # a multi-million-entry memory: independent draws (two of B draws coincide with probability ~B^2 / 2 max_mem per batch)
+        return torch.randint(0, max_mem, (self.batch_size,), generator=self.gen, device=self.device)
+
     def _learn_core(self, max_mem):
         """sampling + TD target + one Adam step (Training_DQN_pytorch.py:156-186); everything on the device, no host sync"""
         self.Q_eval.optimizer.zero_grad(set_to_none=False)
-        batch = torch.randperm(max_mem, generator=self.gen, device=self.device)[:self.batch_size]  # replace=False
+        batch = self._sample(max_mem)
         state_batch = self.state_memory[batch]
         new_state_batch = self.new_state_memory[batch]
         reward_batch = self.reward_memory[batch]
@@ -114,8 +138,14 @@ class BatchedDQNAgent:
 
     def _try_capture(self, max_mem):
         """Once the replay memory is full the learn step has a fixed shape: capture it into a HIP graph (the step is ~25
-        small kernels and launch-bound).  Any failure leaves the eager path in place."""
+        small kernels and launch-bound).  Any failure leaves the eager path in place.  The warm-up iterations PyTorch wants
+        before a capture run with the learning rate at 0 and on a scratch copy of the optimizer state and of the sampling
+        generator, so a graph run makes exactly the updates -- and the random draws -- an eager run makes."""
         self._graph_tried = True
+        opt = self.Q_eval.optimizer
+        saved_opt = copy.deepcopy(opt.state_dict())
+        saved_gen = self.gen.get_state()
+        saved_params = [p.detach().clone() for p in self.Q_eval.parameters()]
         try:
             g = torch.cuda.CUDAGraph()
             if hasattr(g, "register_generator_state"):
@@ -126,15 +156,25 @@ class BatchedDQNAgent:
                 for _ in range(2):
                     self._learn_core(max_mem)
             torch.cuda.current_stream(self.device).wait_stream(side)
+            with torch.no_grad():  # undo the warm-up: parameters, Adam moments / step count, generator
+                for p, q in zip(self.Q_eval.parameters(), saved_params):
+                    p.copy_(q)
+            opt.load_state_dict(saved_opt)
+            self.gen.set_state(saved_gen)
             with torch.cuda.graph(g):
                 self._graph_loss = self._learn_core(max_mem)
             self._graph, self._graph_mem = g, max_mem
         except Exception as ex:  # noqa: BLE001 -- eager is always available
             self._graph = None
+            with torch.no_grad():
+                for p, q in zip(self.Q_eval.parameters(), saved_params):
+                    p.copy_(q)
+            opt.load_state_dict(saved_opt)
+            self.gen.set_state(saved_gen)
             print(f"[dqn] learn() stays eager (graph capture failed: {type(ex).__name__}: {ex})", flush=True)
 
     def learn(self):
-        """One gradient step (Training_DQN_pytorch.py:151-191)."""
+        """One gradient step (Training_DQN_pytorch.py:151-191) + the per-transition schedules (module docstring)."""
         if self.mem_cntr < self.batch_size:
             return None
         max_mem = min(self.mem_size, self.mem_cntr)
@@ -145,6 +185,7 @@ class BatchedDQNAgent:
             loss = self._graph_loss
         else:
             loss = self._learn_core(max_mem)
+        self.updates += 1
         # the reference syncs when mem_cntr hits a multiple of target_update_freq; with N transitions per call the
         # counter jumps, so sync whenever a multiple has been crossed
         if self.mem_cntr >= self._next_target_sync:
@@ -152,7 +193,12 @@ class BatchedDQNAgent:
                 for pt, pe in zip(self.Q_target.parameters(), self.Q_eval.parameters()):
                     pt.copy_(pe)
             self._next_target_sync = (self.mem_cntr // self.target_update_freq + 1) * self.target_update_freq
-        self.epsilon = max(self.epsilon * self.eps_dec, self.eps_end)
+            self.target_syncs += 1
+        # one factor eps_dec per transition stored since the schedule was last charged (reference: per learn() = per transition)
+        n_new = self.mem_cntr - self._eps_cntr
+        if n_new > 0:
+            self.epsilon = max(self.epsilon * math.pow(self.eps_dec, n_new), self.eps_end)
+            self._eps_cntr = self.mem_cntr
         self.last_loss = loss
         return self.last_loss
 
@@ -160,14 +206,19 @@ class BatchedDQNAgent:
     def state_dict(self):
         return dict(q_eval=self.Q_eval.state_dict(), q_target=self.Q_target.state_dict(),
                     optimizer=self.Q_eval.optimizer.state_dict(), epsilon=self.epsilon, mem_cntr=self.mem_cntr,
-                    next_target_sync=self._next_target_sync)
+                    next_target_sync=self._next_target_sync, updates=self.updates, target_syncs=self.target_syncs)
 
     def load_state_dict(self, sd, lr_override=0.0, epsilon_override=0.0, eps_dec_override=0.0):
         self.Q_eval.load_state_dict(sd["q_eval"])
         self.Q_target.load_state_dict(sd["q_target"])
         self.Q_eval.optimizer.load_state_dict(sd["optimizer"])
         self.epsilon = sd["epsilon"]
-        self._next_target_sync = sd.get("next_target_sync", self.target_update_freq)
+        self.updates, self.target_syncs = sd.get("updates", 0), sd.get("target_syncs", 0)
+        # The replay memory is not checkpointed (the reference pickles it with the agent), so the transition counter
+        # restarts at what this process has stored: the sync cadence is re-anchored to THAT counter -- a sync within
+        # target_update_freq transitions of the resume, as in an uninterrupted run -- never to the old run's total.
+        self._eps_cntr = self.mem_cntr
+        self._next_target_sync = (self.mem_cntr // self.target_update_freq + 1) * self.target_update_freq
         if lr_override > 0:  # Training_DQN_pytorch.py:297-303
             for g in self.Q_eval.optimizer.param_groups:
                 g["lr"] = lr_override
@@ -177,30 +228,61 @@ class BatchedDQNAgent:
             self.eps_dec = eps_dec_override
 
 
+@torch.no_grad()
+def evaluate(env, policy, episodes=1):
+    """Mean return per episode of `policy(obs) -> int32 [N]` over every arena of `env` (auto-reset env, time_limit rule):
+    resets, then plays `episodes` full episodes; steps that only re-place an arena carry reward 0."""
+    obs = env.reset()
+    total = torch.zeros(env.num_envs, device=env.device, dtype=torch.float64)
+    T = env.spec.max_episode_steps
+    n_steps = episodes * T + (episodes - 1)  # one re-placing call between consecutive episodes
+    for _ in range(n_steps):
+        obs, reward, done, info = env.step(policy(obs).view(-1, 1))
+        total += reward.double()
+    return float(total.mean() / episodes), float(total.std() / episodes)
+
+
 def train(num_envs=65536, steps=300, preset="T", device="cuda:0", seed=0, checkpoint=None, resume=None,
-          log_every=50, learn=True, mem_size=None, dtype="f64"):
-    """The main loop of Training_DQN_pytorch.py:317-377 over a batched env.  Returns a dict of throughput/score."""
+          log_every=50, learn=True, mem_size=None, dtype="f64", updates_per_step=4, batch_size=None,
+          replay_vector_steps=32, target_sync_vector_steps=64, eps_dec=.999997, eps_end=0.2, eval_every=0,
+          eval_envs=16384, out=None):
+    """The main loop of Training_DQN_pytorch.py:317-377 over a batched env.  Returns a dict of throughput / score /
+    the return curve (greedy policy vs the random policy on a separate evaluation batch, every `eval_every` steps)."""
     import roborugby_amd as rr
     env = rr.make("RoboRugbySimpleDuel-v3", num_envs=num_envs, preset=preset, device=device, seed=seed, dtype=dtype)
     p = env.preset
     if p.game_mode:  # Training_DQN_pytorch.py:233-234
         raise Exception("Game mode settings are enabled in RR_Constants.")
-    agent = BatchedDQNAgent(input_dims=env.observation_space.shape[0], batch_size=env.spec.max_episode_steps * 8 + 100,
-                            n_actions=env.action_space.n, device=device, seed=seed,
-                            max_mem_size=mem_size or max(500000, 8 * num_envs))
+    n_teams = 2 if p.nr_grumpy > 0 else 1
+    B = int(batch_size or min(32768, max(env.spec.max_episode_steps * 8 + 100, num_envs // 2)))
+    agent = BatchedDQNAgent(input_dims=env.observation_space.shape[0], batch_size=B, n_actions=env.action_space.n, device=device,
+                            seed=seed, max_mem_size=mem_size or max(500000, replay_vector_steps * num_envs * n_teams),
+                            target_update_freq=max(100000, target_sync_vector_steps * num_envs * n_teams),
+                            eps_dec=eps_dec, eps_end=eps_end)
     if resume:
         ck = torch.load(resume, map_location=device)
         agent.load_state_dict(ck["agent"])
         st = ck["env_state"]
         env.set_state(st["robots"], st["robots_i"], st["balls"], st["step"])
+        if "episode" in ck:  # episode index (reset RNG key), running returns, counters: the run continues, it does not restart
+            env.set_episode_state(ck["episode"]["ints"], ck["episode"]["acc"])
         observation = env.get_game_state()
     else:
         observation = env.reset()
     grumpy = p.nr_grumpy > 0
     obs_grumpy = env.get_game_state(int_team=-1) if grumpy else None
+    eval_env, curve = None, []
+    if eval_every:
+        eval_env = rr.make("RoboRugbySimpleDuel-v3", num_envs=eval_envs, preset=preset, device=device, seed=seed + 1000003, dtype=dtype)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed + 7)
+        rand_ret, rand_std = evaluate(eval_env, lambda o: torch.randint(0, 8, (o.shape[0],), generator=gen, device=o.device, dtype=torch.int32))
+        curve.append(dict(env_steps=0, vector_steps=0, greedy_return=None, random_return=rand_ret, epsilon=agent.epsilon))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    t_eval = 0.0
     score_sum = torch.zeros(num_envs, device=device)
+    transitions = 0
     for i in range(steps):
         action = agent.choose_action(observation)
         acts = action.view(-1, 1)
@@ -213,26 +295,55 @@ def train(num_envs=65536, steps=300, preset="T", device="cuda:0", seed=0, checkp
             agent.store_transition(observation, action, reward, observation_, done, valid=real)
             if grumpy:
                 agent.store_transition(obs_grumpy, action_grumpy, info.dblGrumpyScore, info.adblGrumpyState, done, valid=real)
-            agent.learn()
+            for _ in range(updates_per_step):
+                agent.learn()
         observation = observation_
         obs_grumpy = info.adblGrumpyState
         if log_every and (i + 1) % log_every == 0:
             lr_, _, ll, cnt = env.episode_stats()
             fin = cnt > 0
             avg = float(lr_[fin].mean()) if bool(fin.any()) else float("nan")
-            print(f"step {i + 1} epsilon {agent.epsilon:.6f} finished-episodes {int(cnt.sum())} "
-                  f"avg-last-return {avg:.1f} loss {float(agent.last_loss) if agent.last_loss is not None else float('nan'):.4f}",
+            print(f"step {i + 1} epsilon {agent.epsilon:.6f} updates {agent.updates} target-syncs {agent.target_syncs} finished-episodes "
+                  f"{int(cnt.sum())} avg-last-return {avg:.1f} loss {float(agent.last_loss) if agent.last_loss is not None else float('nan'):.4f}",
                   flush=True)
+        if eval_every and (i + 1) % eval_every == 0:
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            g_ret, g_std = evaluate(eval_env, lambda o: agent.choose_action(o, epsilon_override=0.0))
+            curve.append(dict(env_steps=(i + 1) * num_envs, vector_steps=i + 1, greedy_return=g_ret, greedy_return_std=g_std,
+                              random_return=rand_ret, epsilon=agent.epsilon, updates=agent.updates, target_syncs=agent.target_syncs))
+            print(f"[eval] after {(i + 1) * num_envs:,} env-steps: greedy return {g_ret:.1f} (random policy {rand_ret:.1f})", flush=True)
+            torch.cuda.synchronize()
+            t_eval += time.perf_counter() - te
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t0 - t_eval
     if checkpoint:
         os.makedirs(os.path.dirname(os.path.abspath(checkpoint)), exist_ok=True)
-        torch.save(dict(agent=agent.state_dict(), env_state=env.get_state()), checkpoint)
+        torch.save(dict(agent=agent.state_dict(), env_state=env.get_state(), episode=env.get_episode_state()), checkpoint)
     lr_, _, ll, cnt = env.episode_stats()
     res = dict(env_steps_per_sec=num_envs * steps / dt, seconds=dt, num_envs=num_envs, steps=steps,
-               learn_calls=steps if learn else 0, epsilon=agent.epsilon, finished_episodes=int(cnt.sum()),
-               mean_step_reward=float(score_sum.mean() / steps))
+               learn_calls=agent.updates, updates_per_step=updates_per_step if learn else 0, batch_size=B,
+               samples_per_transition=(updates_per_step * B / (num_envs * n_teams)) if learn else 0.0,
+               replay_transitions=agent.mem_size, target_update_freq=agent.target_update_freq, target_syncs=agent.target_syncs,
+               epsilon=agent.epsilon, eps_dec=eps_dec, eps_end=eps_end, finished_episodes=int(cnt.sum()),
+               mean_step_reward=float(score_sum.mean() / steps), preset=preset, dtype=dtype, curve=curve)
+    if eval_every:
+        # throughput of the rollout alone under the policy training converged to (greedy, contact-seeking), next to the random policy's
+        for name, pol in (("greedy", lambda o: agent.choose_action(o, epsilon_override=0.0)),
+                          ("random", lambda o: torch.randint(0, 8, (o.shape[0],), device=o.device, dtype=torch.int32))):
+            o = env.reset()
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(200):
+                o, _, _, _ = env.step(pol(o).view(-1, 1))
+            torch.cuda.synchronize()
+            res[f"rollout_env_steps_per_sec_{name}_policy"] = num_envs * 200 / (time.perf_counter() - ts)
+        eval_env.close()
     env.close()
+    if out:
+        os.makedirs(os.path.dirname(os.path.abspath(out)) or ".", exist_ok=True)
+        with open(out, "w") as f:
+            json.dump(res, f, indent=1)
     return res
 
 
@@ -246,9 +357,18 @@ def main():
     ap.add_argument("--checkpoint", default=None)
     ap.add_argument("--resume", default=None)
     ap.add_argument("--no-learn", action="store_true")
+    ap.add_argument("--updates-per-step", type=int, default=4)
+    ap.add_argument("--batch-size", type=int, default=None)
+    ap.add_argument("--eps-dec", type=float, default=.999997)
+    ap.add_argument("--eval-every", type=int, default=0)
+    ap.add_argument("--eval-envs", type=int, default=16384)
+    ap.add_argument("--log-every", type=int, default=50)
+    ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    res = train(a.num_envs, a.steps, a.preset, a.device, a.seed, a.checkpoint, a.resume, learn=not a.no_learn)
-    print(json.dumps(res))
+    res = train(a.num_envs, a.steps, a.preset, a.device, a.seed, a.checkpoint, a.resume, learn=not a.no_learn,
+                updates_per_step=a.updates_per_step, batch_size=a.batch_size, eps_dec=a.eps_dec, eval_every=a.eval_every,
+                eval_envs=a.eval_envs, log_every=a.log_every, out=a.out)
+    print(json.dumps({k: v for k, v in res.items() if k != "curve"}))
 
 
 if __name__ == "__main__":

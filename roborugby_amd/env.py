@@ -93,7 +93,7 @@ class BatchedRoboRugbyEnv:
 
     def __init__(self, num_envs, preset="T", device=None, seed=0, time_limit=True, auto_reset=True, dtype="f64",
                  arena_offset=0, env_id="RoboRugbySimpleDuel-v3", reset_on_fault=None, action_mode="discrete",
-                 rewards=SIMPLE_DUEL3_REWARDS, observer="SingleBall_6wayLidar_v2"):
+                 rewards=SIMPLE_DUEL3_REWARDS, observer="SingleBall_6wayLidar_v2", lst_starting_config=None):
         self.preset = PRESETS[preset] if isinstance(preset, str) else preset
         assert isinstance(self.preset, Preset)
         if not torch.cuda.is_available():
@@ -144,6 +144,26 @@ class BatchedRoboRugbyEnv:
         self.spec = types.SimpleNamespace(id=env_id, max_episode_steps=p.game_len_steps, nondeterministic=True,
                                           reward_threshold=1.0)  # robo_rugby/__init__.py:28-34
         self.has_grumpy = p.nr_grumpy > 0
+        # GameEnv.__init__ (RR_EnvBase.py:111-116): CONFIG_RANDOM keeps what _set_random_positions returned at
+        # construction, a given lst_starting_config ([[(x, y, rot) x NR], [(x, y) x NB]], one layout for every arena or a
+        # pair of [N, ...] arrays) is applied at once; either way reset(bln_randomize_pos=False) goes back to it.
+        if lst_starting_config is None:
+            st = self.get_state()
+            self._start_robots = st["robots"][:, :, [0, 1, 6]].contiguous()
+            self._start_balls = torch.cat([st["balls"][:, :, :2], torch.zeros_like(st["balls"][:, :, :2])], dim=2).contiguous()
+        else:
+            if len(lst_starting_config) != 2:  # RR_EnvBase.py:135-136
+                raise Exception(f"Expected list of 2 lists. Not whatever this is: {lst_starting_config}")
+            r = torch.as_tensor(np.asarray(lst_starting_config[0], dtype=np.float64), device=self.device)
+            b = torch.as_tensor(np.asarray(lst_starting_config[1], dtype=np.float64), device=self.device)
+            if r.shape[-2:] != (p.nr, 3):  # RR_EnvBase.py:138-139
+                raise Exception(f"Robot count mismatch. {p.nr} != {r.shape[-2] if r.dim() >= 2 else r.shape}.")
+            if b.shape[-2:] != (p.nb, 2):  # RR_EnvBase.py:141-142
+                raise Exception(f"Ball count mismatch. {p.nb} != {b.shape[-2] if b.dim() >= 2 else b.shape}.")
+            self._start_robots = r.expand(self.num_envs, p.nr, 3).contiguous()
+            b = b.expand(self.num_envs, p.nb, 2)
+            self._start_balls = torch.cat([b, torch.zeros_like(b)], dim=2).contiguous()
+            self._reset_to_start(None, None)
 
     # ---------------------------------------------------------------- helpers
     @property
@@ -157,16 +177,30 @@ class BatchedRoboRugbyEnv:
         return torch.empty(shape, dtype=dtype, device=self.device)
 
     # ---------------------------------------------------------------- gym surface
-    def reset(self, mask=None):
-        """env.reset() (RR_EnvBase.py:202-216) for all arenas, or those where mask is True."""
+    def _reset_to_start(self, mask, obs):
+        _lib.check(self._lib.rr_reset_to_poses(self._h, _ptr(mask), _ptr(self._start_robots), _ptr(self._start_balls), _ptr(obs),
+                                               None, self._stream()), "rr_reset_to_poses")
+
+    def reset(self, mask=None, bln_randomize_pos=True):
+        """env.reset(bln_randomize_pos) (RR_EnvBase.py:202-216) for all arenas, or those where mask is True: a fresh random
+        placement (_set_random_positions), or with bln_randomize_pos=False the start configuration kept since construction
+        (_set_starting_positions, RR_EnvBase.py:131-153; main.py:107 replays its layout that way)."""
         N = self.num_envs
         obs = self._new((N, 11), torch.float32)
         if mask is not None:
-            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            mask = torch.as_tensor(mask).to(device=self.device, dtype=torch.uint8).contiguous()
             # rows that are not reset keep their current observation
             _lib.check(self._lib.rr_observe(self._h, 1, -1, -1, _ptr(obs), self._stream()), "rr_observe")
-        _lib.check(self._lib.rr_reset(self._h, _ptr(mask), _ptr(obs), None, self._stream()), "rr_reset")
+        if bln_randomize_pos:
+            _lib.check(self._lib.rr_reset(self._h, _ptr(mask), _ptr(obs), None, self._stream()), "rr_reset")
+        else:
+            self._reset_to_start(mask, obs)
         return obs if self.obs_kind == 0 else self.get_game_state(1)
+
+    def starting_positions(self):
+        """The retained start configuration in the reference's format per arena (GameEnv._lst_starting_positions):
+        (robots [N,NR,3] x, y, rot ; balls [N,NB,2] x, y)."""
+        return self._start_robots.clone(), self._start_balls[:, :, :2].clone()
 
     def step(self, actions, out=None):
         """GameEnv_Simple.step for every arena.  actions: int tensor [N] or [N,NA] (NA <= robots; action i drives
@@ -307,6 +341,20 @@ class BatchedRoboRugbyEnv:
                    "rr_get_state")
         return dict(robots=robots, robots_i=robots_i, balls=balls, step=step)
 
+    def get_episode_state(self):
+        """Build-side bookkeeping that a checkpoint has to carry next to get_state(): `ints` [N,5] = episode index (keys the
+        reset RNG: without it a resumed run would replay the placements of episodes 1, 2, ...), steps in the running
+        episode, finished episodes, last episode's length, fault flag; `acc` [N,4] = running / last finished returns."""
+        ints, acc = self._new((self.num_envs, 5), torch.int32), self._new((self.num_envs, 4), torch.float64)
+        _lib.check(self._lib.rr_get_episode_state(self._h, _ptr(ints), _ptr(acc), self._stream()), "rr_get_episode_state")
+        return dict(ints=ints, acc=acc)
+
+    def set_episode_state(self, ints, acc):
+        ints = torch.as_tensor(ints, dtype=torch.int32, device=self.device).contiguous().view(self.num_envs, 5)
+        acc = torch.as_tensor(acc, dtype=torch.float64, device=self.device).contiguous().view(self.num_envs, 4)
+        _lib.check(self._lib.rr_set_episode_state(self._h, _ptr(ints), _ptr(acc), self._stream()), "rr_set_episode_state")
+        torch.cuda.current_stream(self.device).synchronize()
+
     def set_state(self, robots, robots_i, balls, step):
         p, N = self.preset, self.num_envs
         robots = torch.as_tensor(robots, dtype=torch.float64, device=self.device).contiguous().view(N, p.nr, 10)
@@ -358,20 +406,27 @@ class RoboRugbyEnv:
     metadata = BatchedRoboRugbyEnv.metadata
     reward_range = BatchedRoboRugbyEnv.reward_range
 
-    def __init__(self, preset="T", device=None, seed=0, time_limit=True, dtype="f64", action_mode="discrete"):
+    def __init__(self, preset="T", device=None, seed=0, time_limit=True, dtype="f64", action_mode="discrete",
+                 lst_starting_config=None, **kw):
         self._b = BatchedRoboRugbyEnv(1, preset=preset, device=device, seed=seed, time_limit=time_limit,
-                                      auto_reset=False, dtype=dtype, action_mode=action_mode)
+                                      auto_reset=False, dtype=dtype, action_mode=action_mode,
+                                      lst_starting_config=lst_starting_config, **kw)
         self.observation_space = self._b.observation_space
         self.action_space = self._b.action_space
         self.spec = self._b.spec
         self.preset = self._b.preset
+        self._f64 = dtype == "f64" and self._b.obs_kind == 0  # the reference hands out float64 ndarrays
 
     @property
     def unwrapped(self):
         return self
 
     def reset(self, bln_randomize_pos=True):
-        return self._b.reset()[0].double().cpu().numpy()
+        """RR_EnvBase.py:202-216; reset(False) replays the layout kept since construction (main.py:107)."""
+        obs = self._b.reset(bln_randomize_pos=bln_randomize_pos)
+        if self._f64:
+            obs = self._b.get_game_state(1, f64=True)
+        return obs[0].double().cpu().numpy()
 
     def step(self, lstArgs):
         arr = np.concatenate([np.asarray(a).reshape(-1) for a in lstArgs], axis=None) if len(lstArgs) else np.zeros(0)
@@ -382,7 +437,8 @@ class RoboRugbyEnv:
         else:
             if len(arr) > self.preset.nr:
                 raise Exception(f"{len(arr)} commands but only {self.preset.nr} robots.")
-            obs, rew, done, info = self._b.step(torch.as_tensor(arr.astype(np.int64)).view(1, -1))
+            a = torch.as_tensor(arr.astype(np.int64)).view(1, -1)
+            obs, rew, done, info = self._b.step_f64(a) if self._f64 else self._b.step(a)
         st = int(info.status[0]) & STATUS_FLAG_MASK
         for bit, msg in STATUS_BITS.items():
             if st & bit:
@@ -393,7 +449,7 @@ class RoboRugbyEnv:
 
     def get_game_state(self, int_team=None, obj_robot=None, obj_ball=None):
         o = self._b.get_game_state(int_team, -1 if obj_robot is None else int(obj_robot),
-                                   -1 if obj_ball is None else int(obj_ball))
+                                   -1 if obj_ball is None else int(obj_ball), f64=self._f64)
         return None if o is None else o[0].double().cpu().numpy()
 
     def render(self, mode="human"):

@@ -36,7 +36,7 @@ template <typename R> static void fill_params(SimParams<R> &sp, double W, double
     sp.inner_cdist = (R)std::pow(hr * hr + hr * hr, .5);
     sp.game_len = game_len; sp.game_mode = game_mode; sp.time_limit = time_limit; sp.auto_reset = auto_reset & 1;
     sp.reset_on_fault = (auto_reset >> 1) & 1; // bit 1 of the flag word
-    sp.seed = seed; sp.arena_offset = 0; sp.memo = 1;
+    sp.seed = seed; sp.arena_offset = 0; sp.memo = 1; sp.acc_external = 0;
 }
 
 template <class C> static void set_state(Emu<C> *e, const double *robots, const int32_t *ri, const double *balls, int step) {
@@ -147,8 +147,10 @@ template <class CC> static int emu_step_t(Emu<CC> *e, const int32_t *actions, co
     extras_begin<CC>(q, xs);
     StepOut<double> o = { obs, obs_g, reward, reward_g, done, &status, g_dbg_memo ? e->snap : nullptr, e->isnap, 0, 0, 0 };
     step_arena<CC, double>(e->A, e->sp, 0, actions, thrust, na, o);
-    if (e->custom_prog && !(status & (ST_WAS_RESET | ST_STEP_AFTER_DONE)))
-        extras_end<CC, double>(q, e->sp, xs, e->prog, (uint32_t)status >> 16, reward, reward_g, &status);
+    if (e->custom_prog && !(status & (ST_WAS_RESET | ST_STEP_AFTER_DONE))) {
+        RR rh, rg;
+        extras_end<CC, double>(q, e->sp, xs, e->prog, (uint32_t)status >> 16, reward, reward_g, &status, rh, rg);
+    }
     return status;
 }
 } // extern "C++"

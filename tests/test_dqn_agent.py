@@ -31,7 +31,9 @@ def test_store_learn_epsilon_and_target_sync():
         loss = a.learn()
         assert loss is not None and torch.isfinite(loss)
     assert a.mem_cntr == 8 * 90
-    assert abs(a.epsilon - .999997 ** 8) < 1e-12
+    # epsilon decays once per stored TRANSITION (the reference: once per learn() = per transition), not once per call
+    assert abs(a.epsilon - .999997 ** (8 * 90)) < 1e-12 and a.updates == 8
+    assert a.target_syncs == 2  # 300 and 600 stored transitions crossed
     # the ring wrapped (720 < 1000 no; force wrap) and the target network was synced once 300 transitions were stored
     assert not torch.equal(a.Q_target.fc1.weight, w0)
     a.store_transition(torch.rand(400, 11), torch.zeros(400, dtype=torch.int32), torch.zeros(400), torch.rand(400, 11),
@@ -63,13 +65,66 @@ def test_checkpoint_roundtrip():
     assert torch.equal(a.Q_eval.fc3.weight, b.Q_eval.fc3.weight)
 
 
+def test_epsilon_schedule_is_per_transition_at_any_batch_width():
+    """5.4e5 transitions take epsilon from 1.0 to the 0.2 floor (Training_DQN_pytorch.py:186-191 with eps_dec .999997),
+    whether they arrive one per call or 65,536 per call."""
+    import math
+    need = math.log(0.2) / math.log(.999997)
+    for n in (1000, 65536):
+        a = BatchedDQNAgent(device="cpu", batch_size=8, max_mem_size=2 * n)
+        s, z = torch.zeros(n, 11), torch.zeros(n)
+        calls = 0
+        while a.epsilon > 0.2:
+            a.store_transition(s, z.int(), z, s, z.bool())
+            a.learn()
+            calls += 1
+        assert abs(calls - need / n) <= 1.0, (n, calls, need / n)
+
+
+def test_resume_syncs_the_target_within_one_period():
+    """after load_state_dict the sync cadence is anchored to the live transition counter, not the old run's."""
+    a = BatchedDQNAgent(device="cpu", batch_size=8, max_mem_size=4096, target_update_freq=1000)
+    s, z = torch.rand(900, 11), torch.zeros(900)
+    for _ in range(5):  # 4,500 transitions: next sync due at 5,000 in THAT run
+        a.store_transition(s, z.int(), z, s, z.bool())
+        a.learn()
+    assert a._next_target_sync == 5000
+    b = BatchedDQNAgent(device="cpu", batch_size=8, max_mem_size=4096, target_update_freq=1000, seed=9)
+    b.load_state_dict(a.state_dict())
+    assert b.mem_cntr == 0 and b._next_target_sync == 1000
+    w = b.Q_target.fc1.weight.clone()
+    for _ in range(2):  # 1,800 transitions after the resume: one period has passed -> synced
+        b.store_transition(s, z.int(), torch.rand(900), s, z.bool())
+        b.learn()
+    assert b.target_syncs == a.target_syncs + 1 and not torch.equal(b.Q_target.fc1.weight, w)
+
+
 @pytest.mark.gpu
 def test_train_loop_end_to_end_on_gpu(tmp_path):
     from roborugby_amd.dqn import train
     ck = str(tmp_path / "ck.pt")
     res = train(num_envs=4096, steps=12, device="cuda:0", checkpoint=ck, log_every=0)
-    assert res["env_steps_per_sec"] > 1e4 and res["learn_calls"] == 12
+    assert res["env_steps_per_sec"] > 1e4 and res["learn_calls"] == 12 * 4
     res2 = train(num_envs=4096, steps=3, device="cuda:0", resume=ck, log_every=0)
     assert res2["steps"] == 3
     with pytest.raises(Exception, match="Game mode"):
         train(num_envs=64, steps=1, preset="G", device="cuda:0", log_every=0)
+
+
+@pytest.mark.gpu
+def test_config5_trains_at_65536_arenas(tmp_path):
+    """BASELINE config 5 at its stated size: 65,536 arenas of preset T driving the batched DQN loop with learning on --
+    replay filling, k gradient steps per vector step (HIP graph once the memory is full), per-transition schedules -- plus
+    a checkpoint whose resume continues the episodes instead of restarting them."""
+    import roborugby_amd as rr
+    from roborugby_amd.dqn import train
+    ck = str(tmp_path / "ck65536.pt")
+    res = train(num_envs=65536, steps=40, device="cuda:0", checkpoint=ck, log_every=0, replay_vector_steps=8)
+    assert res["num_envs"] == 65536 and res["learn_calls"] == 40 * 4 and res["batch_size"] == 32768
+    assert res["replay_transitions"] == 8 * 65536 and res["epsilon"] == 0.2  # 2.6 M transitions: the floor (5.4e5 suffice)
+    assert res["target_syncs"] == 0 and res["target_update_freq"] == 64 * 65536
+    assert res["env_steps_per_sec"] > 2e6
+    saved = torch.load(ck, map_location="cuda:0")
+    assert int(saved["env_state"]["step"].min()) == 40 and int(saved["episode"]["ints"][:, 1].min()) == 40
+    res2 = train(num_envs=65536, steps=5, device="cuda:0", resume=ck, log_every=0, replay_vector_steps=8)
+    assert res2["steps"] == 5

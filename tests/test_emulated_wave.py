@@ -42,6 +42,33 @@ def test_emulated_kernel_vs_reference_golden(golden_dir, preset, stride, narrow)
 
 
 @pytest.mark.parametrize("preset", ["T", "G"])
+def test_emulated_kernel_thrust_entry_vs_reference_golden(golden_dir, preset):
+    """The kernel's continuous-thrust entry (rr_step_thrust's path in step_arena) against the reference's own
+    GameEnv.step vectors (tests/golden/thrust_*.npz: half-way rounding cases, |thrust| up to 3, fewer pairs than robots)."""
+    t = np.load(f"{golden_dir}/thrust_{preset}.npz")
+    env = el.EmuEnv(preset)
+    worst, n = 0.0, 0
+    for ep in range(t["length"].shape[0]):
+        for s in range(ep % 2, int(t["length"][ep]), 2):
+            env.set_state(t["state_robots"][ep, s], t["state_robots_i"][ep, s], t["state_balls"][ep, s], t["state_step"][ep, s])
+            th = t["thrust"][ep, s]
+            th = th[~np.isnan(th[:, 0])]
+            assert np.array_equal(np.rint(th.astype(np.float32)), np.rint(th))  # the C-ABI takes float32 thrust
+            r = env.step_thrust(th)
+            st = env.get_state()
+            d = _diff(st, t["state_robots"][ep, s + 1], t["state_balls"][ep, s + 1])
+            d = max(d, float(np.abs(r["obs"] - t["obs"][ep, s]).max()))
+            assert np.array_equal(st["robots_i"], t["state_robots_i"][ep, s + 1]), (ep, s)
+            assert d < TOL and abs(r["reward"] - t["reward"][ep, s]) < 1e-7, (preset, ep, s, d)
+            assert r["naughty"] == t["naughty"][ep, s] and r["done"] == bool(t["done"][ep, s])
+            assert (r["status"] & ~256) == 0
+            worst = max(worst, d)
+            n += 1
+    assert n > 250
+    print(f"[{preset}] {n} golden thrust steps through the emulated wave, worst {worst:.2e}")
+
+
+@pytest.mark.parametrize("preset", ["T", "G"])
 def test_emulated_reset_equals_oracle_reset(preset):
     for arena in (0, 5, 123456789):
         e, o = el.EmuEnv(preset, seed=42), ol.OracleEnv(preset)
@@ -112,29 +139,35 @@ def test_time_limit_and_auto_reset_semantics():
     assert r["status"] & 64 and r["done"]  # "Game is over. Go home." (RR_EnvBase.py:261-262)
 
 
-def test_f32_mode_single_step_error_distribution(golden_dir):
-    """fp32 fast mode, one step from synchronised state on the contact-rich fixtures: the median error sits at
-    fp32 round-off (< 1e-5 relative) but contact responses amplify it and a few knife-edge branches flip, so the
-    north-star 1e-5 bound is only claimed for the fp64 mode ("Precision")."""
-    t = np.load(f"{golden_dir}/traj_T.npz")
-    env = el.EmuEnv("T", f32=True)
-    errs = []
-    for ep in range(0, t["length"].shape[0], 2):
-        for s in range(0, int(t["length"][ep]), 5):
-            env.set_state(t["state_robots"][ep, s], t["state_robots_i"][ep, s], t["state_balls"][ep, s], t["state_step"][ep, s])
-            a = t["actions"][ep, s]
-            env.step(a[a >= 0])
-            st = env.get_state()
-            ref = t["state_balls"][ep, s + 1]
-            err = np.abs(st["balls"] - ref) / np.maximum(1.0, np.abs(ref))
-            rr_ = t["state_robots"][ep, s + 1][:, :7]
-            err2 = np.abs(st["robots"][:, :7] - rr_) / np.maximum(1.0, np.abs(rr_))
-            errs.append(max(err.max(), err2.max()))
-    errs = np.array(errs)
-    assert len(errs) > 100
-    assert np.median(errs) < 1e-5
-    assert np.percentile(errs, 90) < 1e-4
-    assert (errs > 1e-2).mean() < 0.01  # branch flips
+@pytest.mark.parametrize("preset,stride", [("T", 2), ("G", 3)])
+def test_f32_mode_single_step_vs_reference_golden(golden_dir, preset, stride):
+    """fp32 fast mode, one step from synchronised state on the reference's golden steps, scored like the GPU test
+    (tests/fp32_checks.py, tests/test_gpu_fp32.py): quiet steps within 1e-5 relative with integer state exact, contact
+    steps inside the documented distribution.  (Host emulation: glibc's sinf/cosf; the GPU test runs ocml's.)"""
+    import fp32_checks as fc
+    t = np.load(f"{golden_dir}/traj_{preset}.npz")
+    cfg = ol.PRESETS[preset]
+    idx = [(ep, s) for ep in range(t["length"].shape[0]) for s in range(ep % stride, int(t["length"][ep]), stride)]
+    ep = np.array([i[0] for i in idx]); s = np.array([i[1] for i in idx])
+    pre = {k: t["state_" + k][ep, s] for k in ("robots", "robots_i", "balls", "step")}
+    post = {k: t["state_" + k][ep, s + 1] for k in ("robots", "robots_i", "balls")}
+    env = el.EmuEnv(preset, f32=True)
+    got = {k: [] for k in post}
+    for i in range(len(idx)):
+        env.set_state(pre["robots"][i], pre["robots_i"][i], pre["balls"][i], pre["step"][i])
+        a = t["actions"][ep[i], s[i]]
+        r = env.step(a[a >= 0])
+        assert r["done"] == bool(t["done"][ep[i], s[i]])
+        st = env.get_state()
+        for k in got:
+            got[k].append(st[k])
+    q, e, ints = fc.score(pre, post, {k: np.array(v) for k, v in got.items()}, cfg["W"], cfg["H"])
+    c = ~q
+    assert q.sum() > 100 and c.sum() > 500
+    assert e[q].max() <= 1e-5 and ints[q].all(), float(e[q].max())
+    assert np.median(e[c]) < 1e-5 and np.percentile(e[c], 90) < 3e-4 and (e[c] > 1e-2).mean() < 0.025 and ints[c].mean() > 0.995
+    print(f"[{preset}] fp32 emulation: {int(q.sum())} quiet steps max {e[q].max():.2e}; {int(c.sum())} contact steps median "
+          f"{np.median(e[c]):.2e} p90 {np.percentile(e[c], 90):.2e}, {100 * (e[c] > 1e-2).mean():.2f} % > 1e-2")
 
 
 def test_reset_on_fault_ends_the_episode(golden_dir):

@@ -195,22 +195,13 @@ def test_single_env_wrapper_behaves_like_the_reference():
         env.step([0])
 
 
-def test_f32_mode_runs_and_tracks_f64():
+def test_f32_handle_refuses_f64_outputs():
+    """(fp32-mode parity lives in tests/test_gpu_fp32.py: reference goldens + the fp64 oracle.)"""
     rr = _rr()
-    n = 4096
-    e64 = rr.BatchedRoboRugbyEnv(n, preset="G", seed=4, dtype="f64")
-    e32 = rr.BatchedRoboRugbyEnv(n, preset="G", seed=4, dtype="f32")
-    o64, o32 = e64.reset(), e32.reset()
-    # same integer draws; a spawn rejection can differ where an int-truncated edge sits on a knife edge
-    err0 = (o64 - o32).abs().max(dim=1).values
-    assert float(err0.median()) < 1e-2 and float((err0 > 1.0).float().mean()) < 0.02
-    a = torch.zeros(n, 4, dtype=torch.int32, device="cuda")
-    o64, r64, _, _ = e64.step(a)
-    o32, r32, _, _ = e32.step(a)
-    err = (o64 - o32).abs().max(dim=1).values
-    assert float(err.median()) < 1e-2 and float((err > 1.0).float().mean()) < 0.03
+    e32 = rr.BatchedRoboRugbyEnv(64, preset="G", seed=4, dtype="f32")
+    e32.reset()
     with pytest.raises(Exception, match="RR_DTYPE_F64"):
-        e32.step_f64(a)
+        e32.step_f64(torch.zeros(64, 4, dtype=torch.int32, device="cuda"))
 
 
 def test_reset_on_fault_replaces_faulted_arenas():
