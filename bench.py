@@ -100,11 +100,10 @@ def main():
     import roborugby_amd as rr
     from roborugby_amd import dist as rrd
 
-    rank, local_rank, world = rrd.init_process_group()
-    if os.environ.get("RR_BENCH_SHARE_GPU"):  # rehearsal of the N>1 path on a 1-GPU box: every rank uses cuda:0
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    # device selection (incl. RR_SHARE_GPU: every rank on cuda:0, the one-GPU rehearsal of the N>1 path) happens inside,
+    # before the process group is created, and RCCL's communicator is bound to that device
+    rank, local_dev, world = rrd.init_process_group()
+    dev = torch.device(f"cuda:{local_dev}")
     n = args.arenas
     env = rr.BatchedRoboRugbyEnv(n, preset=args.preset, device=dev, seed=0, time_limit=True, auto_reset=True,
                                  dtype=args.dtype, arena_offset=rrd.shard_offset(rank, n))

@@ -58,6 +58,9 @@ template <class C> constexpr int arenas_per_block() { return 64 * WAVES_PER_BLOC
 // capping them at 128 VGPRs put ~30 scratch round trips into every sub-step (measured: 487 VMEM instructions per
 // wave-step instead of ~90, and a 0.25 ms latency floor per launch).
 template <class C> constexpr int lds_waves_per_simd() {
+#ifdef RR_FORCE_WAVES // occupancy experiments only (tools/kernel_resources.py ... -DRR_FORCE_WAVES=3)
+    return RR_FORCE_WAVES;
+#endif
     constexpr int per_cu = (160 * 1024) / (int)(sizeof(Arena<C>) * arenas_per_block<C>()) * WAVES_PER_BLOCK;
     return per_cu / 4 < 1 ? 1 : (per_cu / 4 > RR_MIN_WAVES_PER_SIMD ? RR_MIN_WAVES_PER_SIMD : per_cu / 4);
 }

@@ -3,7 +3,8 @@
 Arenas are independent (the reference is single-arena), so rank r simply owns global arenas
 [r*n_local, (r+1)*n_local): the counter-based reset RNG is keyed by the GLOBAL arena id (rr_config.arena_offset),
 which makes every arena's trajectory invariant to how the batch is sharded.  The only exchange is a logging-side
-all-gather of finished-episode returns (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests)."""
+all-gather of finished-episode returns (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests and in the
+one-GPU rehearsal of the N > 1 path)."""
 import os
 
 import torch
@@ -15,22 +16,45 @@ def dist_env():
     return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)))
 
 
+def local_device_index(local_rank):
+    """HIP device of this rank: its local rank -- or 0 for every rank when RR_SHARE_GPU (alias RR_BENCH_SHARE_GPU) asks
+    for the rehearsal of the N > 1 path on a one-GPU box (then with RR_DIST_BACKEND=gloo: RCCL refuses two ranks on one
+    device)."""
+    if os.environ.get("RR_SHARE_GPU") or os.environ.get("RR_BENCH_SHARE_GPU"):
+        return 0
+    return local_rank
+
+
+def _backend():
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
+
+
 def init_process_group(backend=None):
+    """Returns (rank, device_index, world).  The device is selected -- and, for RCCL, bound to the process group
+    (device_id: eager communicator, no "guessing device ID" at the first barrier) -- BEFORE the group exists."""
     rank, local_rank, world = dist_env()
+    dev = local_device_index(local_rank)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(dev)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        # RR_DIST_BACKEND=gloo lets a 1-GPU box rehearse the N>1 path (RCCL refuses two ranks on one device)
         backend = backend or os.environ.get("RR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {}
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    return rank, local_rank, world
+            kw["device_id"] = torch.device("cuda", dev)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, dev, world
 
 
 def shard_offset(rank, n_local):
     """Global id of this rank's arena 0 (contiguous shards of n_local arenas)."""
     return rank * n_local
+
+
+def _comm_tensor(t):
+    """gloo has no device collectives for all_gather: stage through the host (rehearsal / CPU tests only)."""
+    return t.cpu() if (_backend() == "gloo" and t.is_cuda) else t
 
 
 def all_gather_returns(local, async_op=False):
@@ -39,26 +63,37 @@ def all_gather_returns(local, async_op=False):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return (local.clone(), None) if async_op else local.clone()
     world = dist.get_world_size()
-    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    work = dist.all_gather_into_tensor(out, local.contiguous(), async_op=async_op)
+    src = _comm_tensor(local.contiguous())
+    out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    work = dist.all_gather_into_tensor(out, src, async_op=async_op)
+    if src.device != local.device:  # host-staged: hand back a device tensor like the RCCL path does
+        if async_op:
+            work.wait()
+            work = None
+        out = out.to(local.device)
     return (out, work) if async_op else out
+
+
+def _reduce(value, device, op):
+    dev = torch.device("cpu") if _backend() == "gloo" else device
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=op)
+    return float(t.item())
 
 
 def reduce_max(value, device):
     """MAX over ranks of a python float (the timing rule of bench.py)."""
-    t = torch.tensor([value], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    return _reduce(value, device, dist.ReduceOp.MAX)
 
 
 def reduce_sum(value, device):
-    t = torch.tensor([value], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return float(t.item())
+    return _reduce(value, device, dist.ReduceOp.SUM)
 
 
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if _backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()

@@ -69,11 +69,13 @@ def test_dqn_script_call_pattern_reproduces_reference_episodes(golden_dir):
         while not done:
             action = int(t["actions"][ep, s, 0])
             observation_, reward, done, info = env.step([action])
-            assert info.adblGrumpyState is None and info.dblGrumpyScore == 0.0
+            # no grumpy robot on preset T, but PushPosBallsToGoal still books the opposite sign for that team (RR_ScoreKeepers.py:149-153)
+            assert info.adblGrumpyState is None and isinstance(info.dblGrumpyScore, float)
             assert isinstance(reward, float) and isinstance(done, bool)
             score += reward
             if diverged is None and (np.abs(observation_ - t["obs"][ep, s]).max() > 1e-9 or abs(reward - t["reward"][ep, s]) > 1e-7):
                 diverged = s  # chaotic after contacts: see test_free_running_episodes_vs_reference
+            assert diverged is not None or abs(info.dblGrumpyScore - t["reward_g"][ep, s]) < 1e-7
             assert env.render() is None
             s += 1
             # gym's TimeLimit ends the episode at max_episode_steps; the raw env (what the golden recorded) one step later

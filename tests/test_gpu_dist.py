@@ -1,0 +1,104 @@
+"""The N > 1 path, proven on the one GPU there is: two FRESH processes (gloo rendezvous, both on cuda:0, each loading
+libroborugby_amd.so with its own arena_offset) against one process stepping the whole batch; bench.py's own --gpus 2 line;
+and BASELINE config 4's shape -- 524,288 arenas as 8 shards of 65,536 -- shard by shard against the single batch.
+The real 8-GPU run (RCCL over xGMI) is the driver's; these tests make the code it runs correct by construction."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _child_env(port=None, **extra):
+    env = dict(os.environ, RR_SHARE_GPU="1", RR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    if port:
+        env["MASTER_PORT"] = str(port)
+    env.update({k: str(v) for k, v in extra.items()})
+    return env
+
+
+@pytest.mark.timeout(600)
+def test_two_processes_on_one_gpu_equal_one_batch(tmp_path):
+    n, steps, world = 2048, 305, 2  # preset T: 300-step episodes, so every arena reports a finished return
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "dist_child.py"), str(tmp_path), str(n), str(steps)],
+                              env=_child_env(port, RANK=r, LOCAL_RANK=r, WORLD_SIZE=world), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=540)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    res = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
+    assert [r["rank"] for r in res] == [0, 1] and all(r["world"] == 2 and r["backend"] == "gloo" for r in res)
+    assert all(r["lib"] and r["lib"][0].endswith("roborugby_amd/libroborugby_amd.so") for r in res)  # each process loaded the HIP library
+    assert torch.equal(res[0]["returns"], res[1]["returns"]) and res[0]["returns"].shape == (world * n,)
+    assert res[0]["reduce_max"] == 1.0
+    # the same 2n arenas in ONE process: bit for bit
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import dist_child
+    lr, obs, env = dist_child.run_shard(world * n, 0, steps, world * n)
+    assert torch.equal(lr.cpu(), res[0]["returns"])
+    assert torch.equal(obs.cpu(), res[0]["obs"])
+    env.close()
+
+
+@pytest.mark.timeout(900)
+def test_bench_gpus_2_prints_a_well_formed_line():
+    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one rank per 'GPU'), both ranks sharing
+    cuda:0 with gloo standing in for RCCL."""
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5",
+           "--arenas", "16384", "--log-interval", "10"]
+    p = subprocess.run(cmd, env=_child_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=840, cwd=REPO)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]  # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 30 and line["warmup"] == 5 and line["scaling"] == "weak"
+    assert line["metric"] == "env_steps_per_sec" and line["unit"] == "env-steps/s" and line["higher_is_better"] is True
+    # whole-job value = both shards' steps / max-over-ranks time
+    assert abs(line["value"] - 2 * 16384 * 30 / (line["ms_per_step"] * 30e-3)) / line["value"] < 0.02
+    assert line["config"]["arenas_per_gpu"] == 16384 and "dp2" in line["config"]["sharding"]
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+    assert "cpu_baseline" not in line  # rank 0 at N = 1 only
+
+
+@pytest.mark.timeout(900)
+def test_config4_shape_eight_shards_of_65536_equal_one_batch_of_524288():
+    """BASELINE config 4's partitioning on one GPU: arenas [r*65,536, (r+1)*65,536) created with arena_offset reproduce the
+    matching slice of ONE 524,288-arena batch bit for bit (placement by global arena id, then 3 steps)."""
+    import roborugby_amd as rr
+    n, world = 65536, 8
+    g = torch.Generator(device="cuda").manual_seed(77)
+    acts = torch.randint(0, 8, (3, world * n, 4), generator=g, device="cuda", dtype=torch.int32)
+
+    def run(num, offset):
+        env = rr.BatchedRoboRugbyEnv(num, preset="G", seed=2026, arena_offset=offset, reset_on_fault=False)
+        o = env.reset()
+        for s in range(3):
+            o, r, d, info = env.step(acts[s, offset:offset + num])
+        st = env.get_state()
+        env.close()
+        return o, r, st["robots"], st["balls"]
+
+    big = run(world * n, 0)
+    for r in range(world):
+        part = run(n, r * n)
+        for a, b in zip(part, big):
+            b = b[r * n:(r + 1) * n]
+            assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0)), r
