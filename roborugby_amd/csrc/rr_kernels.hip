@@ -61,6 +61,9 @@ template <class C> constexpr int lds_waves_per_simd() {
 #ifdef RR_FORCE_WAVES // occupancy experiments only (tools/kernel_resources.py ... -DRR_FORCE_WAVES=3)
     return RR_FORCE_WAVES;
 #endif
+#ifdef RR_FORCE_WAVES // occupancy experiments only (tools/kernel_resources.py ... -DRR_FORCE_WAVES=3)
+    return RR_FORCE_WAVES;
+#endif
     constexpr int per_cu = (160 * 1024) / (int)(sizeof(Arena<C>) * arenas_per_block<C>()) * WAVES_PER_BLOCK;
     return per_cu / 4 < 1 ? 1 : (per_cu / 4 > RR_MIN_WAVES_PER_SIMD ? RR_MIN_WAVES_PER_SIMD : per_cu / 4);
 }
@@ -74,7 +77,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
                                                               const float *thrust, int na, O *obs, O *reward,
                                                               uint8_t *done, O *obs_g, O *reward_g, int32_t *status,
                                                               const uint32_t *order, uint32_t *cost, int nsteps, int repeat) {
+#ifdef RR_FAKE_LDS_ARENAS // resource experiments only (never run): what the register allocator does when LDS stops capping the occupancy
+    __shared__ Arena<C> lds[RR_FAKE_LDS_ARENAS];
+#else
     __shared__ Arena<C> lds[arenas_per_block<C>()];
+#endif
     const int wave = threadIdx.x / C::VW; // virtual wave = arena slot in this workgroup
     // slowest-first dispatch: workgroup b steps the group of arenas that was the b-th slowest in the previous step
     const unsigned long long t_begin = cost ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -368,7 +375,9 @@ __global__ void k_observe_kind(SimParams<typename C::Real> sp, const typename C:
 // ------------------------------------------------------------------------------------------------ host side
 // Built configurations: (kind = shape + 2*dtype, entity counts, Real, VW).  The first VW listed for a kind is the
 // default; the environment variable RR_VW selects another built width (kernel tuning / A-B runs).
-#ifdef RR_CFG_SUBSET // tuning builds only (tools/build_variant.sh): the two default configurations, quick to compile
+#if defined(RR_CFG_SUBSET) && RR_CFG_SUBSET == 2 // occupancy probe: T at 4 lanes per arena (its LDS admits 4 waves per SIMD)
+#define RR_FOR_EACH_CFG(X) X(0, 1, 0, 1, 0, double, 4) X(1, 2, 2, 4, 4, double, 8)
+#elif defined(RR_CFG_SUBSET) // tuning builds only (tools/build_variant.sh): the two default configurations, quick to compile
 #define RR_FOR_EACH_CFG(X) X(0, 1, 0, 1, 0, double, 2) X(1, 2, 2, 4, 4, double, 8)
 #else
 #define RR_FOR_EACH_CFG(X)                                                                             \

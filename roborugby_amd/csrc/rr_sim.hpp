@@ -1202,7 +1202,7 @@ template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimPar
     while (naughty) {
         count++;
         work++;
-        if (count > 10) return false;
+        if (count > 10) { RR_TRACE("E resolve gave up\n"); return false; }
         naughty = false;
         uint64_t bb = detect_ball_pairs(A);
 #pragma unroll 1
@@ -1233,6 +1233,7 @@ template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimPar
             RR_SYNC();
         }
     }
+    RR_TRACE("E resolve done in %d passes\n", count);
     return true;
 }
 template <class C>
@@ -1266,6 +1267,7 @@ RR_HDN void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real>
         naughty = (nbots | nballs) != 0;
         hit.r |= nbots; hit.b |= nballs;
         uint32_t ubots = bots_moved & nbots, uballs = balls_moved & nballs;
+        RR_TRACE("E undo iteration %d: contacts r %x b %x, undone r %x b %x\n", count, nbots, nballs, ubots, uballs);
         bots_moved &= ~ubots;
         balls_moved &= ~uballs;
         if (ubots | uballs) {
@@ -1509,6 +1511,7 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     // runs in the same phase as the roll, so the other ball may be seen before or after its own roll: the bound (A.reach,
     // written at the frame hooks and refreshed by the push) adds the most it can travel in its roll.  Ball-robot uses the settled robot centres; the wall test is the exact int-rect test.
     uint64_t m_any = 0;
+    RR_TRACE("E phase1 rr %d br %d\n", (int)(m_rr != 0), (int)(m_br != 0));
     if (frozen && (fz.r | fz.b)) substep_phase2<C, true>(A, sp, fz, m_any);
     else substep_phase2<C, false>(A, sp, fz, m_any);
     RR_SYNC();
@@ -1526,6 +1529,7 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
         RR_FOR_LANES(l) { if (l < C::NB && ((k.b >> l) & 1u)) ball_move_lane(A, l); }
         RR_SYNC();
     }
+    RR_TRACE("E phase2 any %d\n", (int)(m_any != 0));
     if (m_any) { // the reference's loop, from its first pass (nothing has changed since the broad phase above)
         bool rr_ok_ = resolve_ball_collisions(A, sp, bots_moved, st, work, hit);
         RR_STAMP(5);

@@ -131,3 +131,21 @@ def test_config5_trains_at_65536_arenas(tmp_path):
     assert int(ints[:, 0].min()) >= 1                          # episode index: keys the reset RNG after the resume
     res2 = train(num_envs=65536, steps=5, device="cuda:0", resume=ck, log_every=0, replay_vector_steps=8)
     assert res2["steps"] == 5
+
+
+@pytest.mark.gpu
+def test_config5_learns_to_beat_the_random_policy():
+    """Two episodes' worth of vector steps at 65,536 arenas (39 M env-steps, a few seconds): the greedy policy's mean episode
+    return on a separate evaluation batch is far above the random policy's (profiles/r02/dqn_T_65536.json holds the long curve:
+    random 119, greedy 4,003 after one episode, ~30,000 after ten; the reference's own bar is "Avg score 1800 @ ~450 games",
+    Training_DQN_pytorch.py:240-249)."""
+    from roborugby_amd.dqn import train
+    res = train(num_envs=65536, steps=600, device="cuda:0", log_every=0, eval_every=300, eval_envs=8192)
+    curve = res["curve"]
+    assert len(curve) == 3 and curve[0]["greedy_return"] is None
+    rand = curve[0]["random_return"]
+    best = max(c["greedy_return"] for c in curve[1:])
+    print(f"random policy {rand:.0f}, greedy after 300 / 600 vector steps {curve[1]['greedy_return']:.0f} / {curve[2]['greedy_return']:.0f}; "
+          f"training {res['env_steps_per_sec'] / 1e6:.1f} M env-steps/s, greedy rollout {res['rollout_env_steps_per_sec_greedy_policy'] / 1e6:.1f} M")
+    assert abs(rand) < 1000 and best > rand + 1500
+    assert res["epsilon"] == 0.2 and res["learn_calls"] == 2400
