@@ -6,10 +6,10 @@
 // is no workgroup barrier anywhere and no inter-workgroup traffic -- any blockIdx -> XCD placement is equally
 // good (arenas share nothing, there is no L2 reuse to protect).  65,536 arenas = 2,048..65,536 workgroups.
 //
-// HBM layout: one record of P_STRIDE reals + one of I_STRIDE int32 per arena, both padded to 128-B
-// multiples.  Inside a record the fields are entity-minor (SoA over robots / balls), and a wave
-// loads/stores its record with lane-strided accesses: lane k touches word k, so every wave-level
-// load is one contiguous, aligned run of 512 B (fp64) / 256 B (fp32).
+// HBM layout: one record per arena -- the persistent reals (Arena::P) with the int32 bookkeeping (Arena::I) right behind
+// them, padded to a 64-B multiple (G/fp64: 960 B, T/fp64: 256 B).  Inside a record the fields are entity-minor (SoA over
+// robots / balls), and an arena's lanes load/store it with lane-strided accesses: lane k touches word k, so every
+// wave-level access covers one contiguous run per arena that starts on a 64-B boundary.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
@@ -42,7 +42,10 @@ template <class C> __device__ __forceinline__ void store_record(const Arena<C> &
     const int lane = threadIdx.x & (C::VW - 1);
     RR_SYNC();
     for (int k = lane; k < Arena<C>::P_REALS; k += C::VW) rec[k] = p[k];
-    for (int k = lane; k < Arena<C>::I_INTS; k += C::VW) irec[k] = q[k];
+    // the ints and the record's padding: the whole 64-B tail is written, so no line of the record is left partially
+    // dirty (a partial line costs a read-for-merge in L2: 0.3 KB per env-step showed up in FETCH_SIZE)
+    constexpr int TAIL = Arena<C>::I_STRIDE - Arena<C>::P_REALS * Arena<C>::WR;
+    for (int k = lane; k < TAIL; k += C::VW) irec[k] = k < Arena<C>::I_INTS ? q[k] : 0;
 }
 
 #ifndef RR_MIN_WAVES_PER_SIMD
@@ -76,7 +79,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
                                                               int32_t *irecs, int n, const int32_t *actions,
                                                               const float *thrust, int na, O *obs, O *reward,
                                                               uint8_t *done, O *obs_g, O *reward_g, int32_t *status,
-                                                              const uint32_t *order, uint32_t *cost, int nsteps, int repeat) {
+                                                              const uint32_t *order, uint32_t *cost, int nsteps, int repeat,
+                                                              uint32_t *snap, int32_t *isnap) {
 #ifdef RR_FAKE_LDS_ARENAS // resource experiments only (never run): what the register allocator does when LDS stops capping the occupancy
     __shared__ Arena<C> lds[RR_FAKE_LDS_ARENAS];
 #else
@@ -99,8 +103,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
     derive(A, sp);
     RR_STAMP(12);
     if constexpr (!MULTI) {
-        StepOut<O> o = { obs, obs_g, reward, reward_g, done, status, sp.memo ? reinterpret_cast<uint32_t *>(recs) : nullptr, irecs, arena,
-                         (int)(Arena<C>::P_STRIDE * sizeof(typename C::Real) / 4), (int)Arena<C>::I_STRIDE };
+        StepOut<O> o = { obs, obs_g, reward, reward_g, done, status, sp.memo ? snap : nullptr, isnap, arena,
+                         (int)Arena<C>::SNAP_WORDS, (int)Arena<C>::ISNAP_WORDS };
         step_arena<C, O>(A, sp, sp.arena_offset + (uint64_t)arena, actions ? actions + (size_t)arena * na : nullptr,
                          thrust ? thrust + (size_t)arena * 2 * na : nullptr, na, o);
     } else {
@@ -110,8 +114,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
         for (int s = 0; s < nsteps; s++) {
             const size_t so = (size_t)s * (size_t)n;
             StepOut<O> o = { obs + so * 11, obs_g ? obs_g + so * 11 : nullptr, reward + so, reward_g ? reward_g + so : nullptr, done + so,
-                             status ? status + so : nullptr, sp.memo ? reinterpret_cast<uint32_t *>(recs) : nullptr, irecs, arena,
-                             (int)(Arena<C>::P_STRIDE * sizeof(typename C::Real) / 4), (int)Arena<C>::I_STRIDE };
+                             status ? status + so : nullptr, sp.memo ? snap : nullptr, isnap, arena,
+                             (int)Arena<C>::SNAP_WORDS, (int)Arena<C>::ISNAP_WORDS };
             const size_t ao = repeat ? 0 : so;
             step_arena<C, O>(A, sp, sp.arena_offset + (uint64_t)arena, actions ? actions + (ao + (size_t)arena) * na : nullptr,
                              thrust ? thrust + (ao + (size_t)arena) * 2 * na : nullptr, na, o);
@@ -392,8 +396,10 @@ struct rr_env {
     int kind; // 0 T64, 1 G64, 2 T32, 3 G32
     int vw;   // lanes per arena
     void *recs;
-    int32_t *irecs;
+    int32_t *irecs;      // the int part of the records: recs + P_REALS (same allocation, same stride)
     size_t rec_bytes, irec_bytes;
+    uint32_t *snap;      // fixed-point snapshots (null when the shortcuts are off)
+    int32_t *isnap;
     SimParams<double> spd;
     SimParams<float> spf;
     Program prog;        // reward keepers in execution order
@@ -490,18 +496,28 @@ int rr_create(const rr_config *cfg, rr_env **out) {
 #undef X
     fill_params(e->spd, *cfg);
     fill_params(e->spf, *cfg);
-    size_t pstride = 0, istride = 0;
+    size_t pstride = 0, preals = 0, snapw = 0, isnapw = 0;
     const size_t rsz = cfg->dtype == RR_DTYPE_F32 ? 4 : 8;
-    dispatch(e, [&](auto c) { using CC = decltype(c); pstride = Arena<CC>::P_STRIDE; istride = Arena<CC>::I_STRIDE; return 0; });
+    dispatch(e, [&](auto c) {
+        using CC = decltype(c);
+        pstride = Arena<CC>::P_STRIDE; preals = Arena<CC>::P_REALS; snapw = Arena<CC>::SNAP_WORDS; isnapw = Arena<CC>::ISNAP_WORDS;
+        return 0;
+    });
     e->rec_bytes = pstride * rsz;
-    e->irec_bytes = istride * 4;
+    e->irec_bytes = 0; // inside the record
+    e->snap = nullptr; e->isnap = nullptr;
     hipError_t he = hipMalloc(&e->recs, e->rec_bytes * (size_t)cfg->num_envs);
-    if (he == hipSuccess) he = hipMalloc((void **)&e->irecs, e->irec_bytes * (size_t)cfg->num_envs);
+    if (he == hipSuccess && e->spd.memo) { // scratch of the exact shortcuts (RR_NO_MEMO=1: off)
+        he = hipMalloc((void **)&e->snap, 4 * snapw * (size_t)cfg->num_envs);
+        if (he == hipSuccess) he = hipMalloc((void **)&e->isnap, 4 * isnapw * (size_t)cfg->num_envs);
+    }
     if (he != hipSuccess) {
         if (e->recs) (void)hipFree(e->recs);
+        if (e->snap) (void)hipFree(e->snap);
         delete e;
         return fail(-3, std::string("rr_create: hipMalloc: ") + hipGetErrorString(he));
     }
+    e->irecs = reinterpret_cast<int32_t *>(static_cast<char *>(e->recs) + preals * rsz);
     const int n = cfg->num_envs;
     // slowest-first dispatch pays once the groups outnumber the wavefronts resident at a time (a few thousand); one
     // workgroup sorts up to 65,536 keys in a few microseconds.  RR_NO_ORDER=1 switches it off (A/B runs).
@@ -532,7 +548,9 @@ int rr_create(const rr_config *cfg, rr_env **out) {
     he = hipGetLastError();
     if (he == hipSuccess) he = hipDeviceSynchronize();
     if (he != hipSuccess) {
-        (void)hipFree(e->recs); (void)hipFree(e->irecs);
+        (void)hipFree(e->recs);
+        if (e->snap) (void)hipFree(e->snap);
+        if (e->isnap) (void)hipFree(e->isnap);
         if (e->order) (void)hipFree(e->order);
         if (e->cost) (void)hipFree(e->cost);
         delete e;
@@ -546,7 +564,8 @@ int rr_destroy(rr_env *e) {
     if (!e) return 0;
     DeviceGuard guard(e->cfg.device);
     (void)hipFree(e->recs);
-    (void)hipFree(e->irecs);
+    if (e->snap) (void)hipFree(e->snap);
+    if (e->isnap) (void)hipFree(e->isnap);
     if (e->xs) (void)hipFree(e->xs);
     if (e->status_buf) (void)hipFree(e->status_buf);
     if (e->order) (void)hipFree(e->order);
@@ -600,11 +619,11 @@ static int step_impl(rr_env *e, const int32_t *actions, const float *thrust, int
             if (nsteps == 1)
                 hipLaunchKernelGGL((k_step<CC, O, false>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (RR *)e->recs, e->irecs, n,
                                    actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status, (const uint32_t *)e->order, e->cost,
-                                   1, 0);
+                                   1, 0, e->snap, e->isnap);
             else if constexpr (std::is_same<O, float>::value && (CC::NR == 1 ? CC::VW == 2 : CC::VW == 8)) // default lane widths only (build time)
                 hipLaunchKernelGGL((k_step<CC, O, true>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (RR *)e->recs, e->irecs, n,
                                    actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status, (const uint32_t *)e->order, e->cost,
-                                   nsteps, repeat);
+                                   nsteps, repeat, e->snap, e->isnap);
             else
                 return fail(-1, "rr_rollout: built for float outputs and the default lane widths (RR_VW unset) only");
             if (e->order) hipLaunchKernelGGL(k_order, dim3(1), dim3(ORDER_THREADS), 0, s, (const uint32_t *)e->cost, e->order, e->ngroups);

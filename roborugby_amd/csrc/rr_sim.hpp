@@ -373,8 +373,14 @@ template <class C> struct ArenaBody {
 #endif
     static constexpr int P_REALS = (int)(sizeof(P) / sizeof(R));
     static constexpr int I_INTS = (int)(sizeof(I) / sizeof(int32_t));
-    static constexpr int P_STRIDE = (P_REALS + 3 * NR + 15) / 16 * 16; // record strides in HBM (128-B multiples; room for the fixed-point snapshot)
-    static constexpr int I_STRIDE = (I_INTS + 15) / 16 * 16;
+    // HBM record of one arena: the P reals, the I ints right behind them, padded to a 64-B multiple (so that the lane-strided
+    // runs of the arenas sharing a wavefront start on request boundaries).  G/fp64: 108 reals + 18 ints = 936 -> 960 B.
+    static constexpr int WR = (int)(sizeof(R) / 4);                       // 32-bit words per real
+    static constexpr int P_ALIGN = 64 / (int)sizeof(R);
+    static constexpr int P_STRIDE = (P_REALS + (I_INTS + WR - 1) / WR + P_ALIGN - 1) / P_ALIGN * P_ALIGN; // reals per record
+    static constexpr int I_STRIDE = P_STRIDE * WR;                         // the same stride seen from the int part (irecs = recs + P_REALS)
+    // fixed-point snapshot (its own buffer, touched only by arenas that ran the expensive contact paths): P + ax, ay, arot
+    static constexpr int SNAP_WORDS = (P_REALS + 3 * NR) * WR, ISNAP_WORDS = 2 * NR;
 };
 // LDS bank spreading.  The 64/VW arenas of a wavefront sit in consecutive LDS slices and their lanes touch the SAME
 // field at the same time, so the slice stride decides the banking: lane-strided accesses of one arena cover
@@ -1890,7 +1896,7 @@ template <typename O> struct StepOut {
     O *obs_base, *obs_g_base, *reward_base, *reward_g_base;
     uint8_t *done_base;
     int32_t *status_base;
-    uint32_t *snap_base = nullptr; // the arena records in HBM: scratch for the fixed-point check (null: shortcuts off)
+    uint32_t *snap_base = nullptr; // per-arena scratch in HBM for the fixed-point check (null: shortcuts off)
     int32_t *isnap_base = nullptr;
     int arena = 0;
     int snap_stride = 0, isnap_stride = 0; // words per arena
@@ -1913,8 +1919,8 @@ template <typename O> struct StepOut {
 // so if all of that after sub-step k is bit-identical to what it was after sub-step k-1, sub-step k+1 gets the very
 // input sub-step k got, and by induction every later sub-step of this step reproduces the same state (and ORs the
 // same bits into `naughty` / `st`): the loop can stop.  Exact, not approximate.
-// The comparison is bitwise (NaN-safe), lane-strided, against a snapshot kept in the arena's own HBM record (dead
-// between load_record and store_record); it is only made after sub-steps that ran the expensive contact paths.
+// The comparison is bitwise (NaN-safe), lane-strided, against a snapshot kept in a per-arena scratch buffer in HBM; it is
+// only made after sub-steps that ran the expensive contact paths, so quiet arenas never touch that buffer.
 // did the last move of any robot in `mask` end in the 0.5-px wall clamp (RR_Robot.py:195-203)?
 template <class C> RR_HD bool robots_clamped(const Arena<C> &A, uint32_t mask) {
     uint64_t any = 0;
@@ -1944,7 +1950,7 @@ RR_HD void snapshot_compare_update(const Arena<C> &A, uint32_t *snap, int32_t *i
     constexpr int WR = (int)(sizeof(R) / 4);
     constexpr int NW = (int)(sizeof(typename Arena<C>::P) / 4);   // the persistent reals ...
     constexpr int NA = 3 * C::NR * WR;                            // ... + ax, ay, arot: the frame-begin poses the next sub-step's ring update reads
-    static_assert(Arena<C>::P_STRIDE * sizeof(R) / 4 >= (size_t)(NW + NA), "the HBM record holds the snapshot");
+    static_assert(Arena<C>::SNAP_WORDS == NW + NA, "snapshot buffer stride");
     static_assert(offsetof(ArenaBody<C>, ay) == offsetof(ArenaBody<C>, ax) + C::NR * sizeof(R) &&
                   offsetof(ArenaBody<C>, arot) == offsetof(ArenaBody<C>, ax) + 2 * C::NR * sizeof(R), "ax, ay, arot are contiguous");
     const uint32_t *p = reinterpret_cast<const uint32_t *>(&A.p);

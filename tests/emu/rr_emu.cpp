@@ -20,7 +20,7 @@ template <class C> struct Emu {
     SimParams<typename C::Real> sp;
     Program prog;     // reward keepers in execution order (default = SimpleDuel3)
     bool custom_prog;
-    uint32_t snap[Arena<C>::P_STRIDE * sizeof(typename C::Real) / 4];
+    uint32_t snap[Arena<C>::SNAP_WORDS];
     typename C::Real xs[3 * C::NR + 1 + 2 * C::NB]; // on_step_begin snapshot (always taken here: AllCoords_WithPrior reads it)
     int32_t isnap[2 * C::NR];
 };
