@@ -55,7 +55,11 @@ template <class C> __device__ __forceinline__ void store_record(const Arena<C> &
 #define RR_WAVES_PER_BLOCK 1 // arenas never cooperate across wavefronts, so a workgroup IS a wavefront (finer dispatch: +9 % measured)
 #endif
 constexpr int WAVES_PER_BLOCK = RR_WAVES_PER_BLOCK;
+#ifdef RR_ARENAS_PER_WAVE // occupancy probe only: fewer arenas per wavefront (idle lanes) so that LDS admits a third wave per SIMD
+template <class C> constexpr int arenas_per_block() { return (C::VW == 8 ? RR_ARENAS_PER_WAVE : 64 / C::VW) * WAVES_PER_BLOCK; }
+#else
 template <class C> constexpr int arenas_per_block() { return 64 * WAVES_PER_BLOCK / C::VW; }
+#endif
 // Waves per SIMD the 160 KiB of LDS admit for this configuration.  Asking the register allocator for more than that
 // (launch bounds) only buys spills: with 17 KB of LDS per wavefront G/VW=8 and T/VW=2 top out at 2 waves/SIMD, and
 // capping them at 128 VGPRs put ~30 scratch round trips into every sub-step (measured: 487 VMEM instructions per
@@ -87,6 +91,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
     __shared__ Arena<C> lds[arenas_per_block<C>()];
 #endif
     const int wave = threadIdx.x / C::VW; // virtual wave = arena slot in this workgroup
+#ifdef RR_ARENAS_PER_WAVE
+    if (wave >= arenas_per_block<C>()) return;
+#endif
     // slowest-first dispatch: workgroup b steps the group of arenas that was the b-th slowest in the previous step
     const unsigned long long t_begin = cost ? __builtin_amdgcn_s_memtime() : 0ull;
     const int group = order ? (int)order[blockIdx.x] : (int)blockIdx.x;
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_reset(SimParams<typena
     __shared__ Arena<C> lds[arenas_per_block<C>()];
     const int wave = threadIdx.x / C::VW; // virtual wave = arena slot in this workgroup
     const int arena = blockIdx.x * arenas_per_block<C>() + wave;
-    if (arena >= n) return;
+    if (arena >= n || wave >= arenas_per_block<C>()) return;
     Arena<C> &A = lds[wave];
     R *rec = recs + (size_t)arena * Arena<C>::P_STRIDE;
     int32_t *irec = irecs + (size_t)arena * Arena<C>::I_STRIDE;
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_observe(SimParams<type
     __shared__ Arena<C> lds[arenas_per_block<C>()];
     const int wave = threadIdx.x / C::VW; // virtual wave = arena slot in this workgroup
     const int arena = blockIdx.x * arenas_per_block<C>() + wave;
-    if (arena >= n) return;
+    if (arena >= n || wave >= arenas_per_block<C>()) return;
     Arena<C> &A = lds[wave];
     load_record(A, recs + (size_t)arena * Arena<C>::P_STRIDE, irecs + (size_t)arena * Arena<C>::I_STRIDE);
     derive(A, sp);
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_set_poses(SimParams<ty
     __shared__ Arena<C> lds[arenas_per_block<C>()];
     const int wave = threadIdx.x / C::VW, lane = threadIdx.x & (C::VW - 1);
     const int arena = blockIdx.x * arenas_per_block<C>() + wave;
-    if (arena >= n) return;
+    if (arena >= n || wave >= arenas_per_block<C>()) return;
     if (mask && !mask[arena]) return; // uniform per virtual wave
     Arena<C> &A = lds[wave];
     R *rec = recs + (size_t)arena * Arena<C>::P_STRIDE;

@@ -107,6 +107,9 @@ __device__ unsigned long long g_rr_wave_t[2 * 65536]; // [start, end] s_memtime 
 #define RR_TRACE(...) do { } while (0)
 #endif
 
+// rare branches (contact paths, reset, frozen islands): tells the register allocator where spilling is cheap
+#define RR_UNLIKELY(x) __builtin_expect(!!(x), 0)
+
 #ifndef RR_NUM_SUBSTEPS
 #define RR_NUM_SUBSTEPS 12 // MOVES_PER_FRAME (RR_Constants.py:13); only the emulation harness overrides it to bisect
 #endif
@@ -708,7 +711,7 @@ template <class C> RR_HD uint32_t detect_robot_pairs(Arena<C> &A) {
         }
         close |= (uint32_t)(m << base);
     }
-    if (!close) return 0;
+    if (!RR_UNLIKELY(close)) return 0;
     ensure_sides(A);
     // narrow phase: the 16 (side, side) tests of each close pair, VW of them per round
     uint32_t pairs = 0;
@@ -758,7 +761,7 @@ template <class C, bool CACHED> RR_HD uint32_t detect_ball_robot(Arena<C> &A, co
         }
         RR_VOTE(anyc, l, c);
     }
-    if (!anyc) return 0;
+    if (!RR_UNLIKELY(anyc)) return 0;
     RR_SYNC();
     uint32_t close = 0;
     for (int b = 0; b < C::NB; b++) close |= (uint32_t)A.brc[b] << (b * C::NR);
@@ -837,7 +840,7 @@ template <class C> RR_HD uint64_t detect_ball_pairs(Arena<C> &A) {
         }
         RR_VOTE(anyh, l, h);
     }
-    if (!anyh) return 0;
+    if (!RR_UNLIKELY(anyh)) return 0;
     RR_SYNC();
     uint64_t mask = 0; // bit p of the nested-loop pair order (i < j)
     int p = 0;
@@ -1493,21 +1496,21 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     // displacement a move can cause (1 px drive / 0.17 px pivot / <= 1.5 px wall clamp: 3 px per robot is generous).
     uint64_t m_rr = 0, m_br = 0, m_wm = 0;
     const bool frozen = (fz.r | fz.b) != 0; // the frozen variants are separate instantiations: the common path pays nothing
-    if (frozen) substep_phase1<C, true>(A, sp, fz, prev_moved, m_rr, m_br, m_wm);
+    if (RR_UNLIKELY(frozen)) substep_phase1<C, true>(A, sp, fz, prev_moved, m_rr, m_br, m_wm);
     else substep_phase1<C, false>(A, sp, fz, prev_moved, m_rr, m_br, m_wm);
     RR_SYNC();
     RR_STAMP(1);
-    if ((fz.r | fz.b) && (m_rr | m_br | m_wm)) { // thaw before anything depended on the island
+    if (RR_UNLIKELY((fz.r | fz.b) && (m_rr | m_br | m_wm))) { // thaw before anything depended on the island
         RR_TRACE("E thaw in phase 1\n");
         thaw_island(A, sp, fz, bots_moved);
         m_rr = 1; m_br = 1;
     }
-    if (m_rr) {
+    if (RR_UNLIKELY(m_rr)) {
         resolve_bot_collisions(A, sp, bots_moved, naughty, st, work, hit);
         m_br = 1; // an undone robot changes the ball-robot picture: let the full detection decide
     }
     RR_STAMP(2);
-    if (m_br) { // _push_balls (RR_EnvBase.py:335-339): frozen hit list, ball-major order
+    if (RR_UNLIKELY(m_br)) { // _push_balls (RR_EnvBase.py:335-339): frozen hit list, ball-major order
         uint32_t br = detect_ball_robot<C, false>(A, sp);
         RR_TRACE("E push mask %08x\n", br);
         push_balls(A, sp, br, bots_moved, st, hit);
@@ -1518,11 +1521,11 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     // written at the frame hooks and refreshed by the push) adds the most it can travel in its roll.  Ball-robot uses the settled robot centres; the wall test is the exact int-rect test.
     uint64_t m_any = 0;
     RR_TRACE("E phase1 rr %d br %d\n", (int)(m_rr != 0), (int)(m_br != 0));
-    if (frozen && (fz.r | fz.b)) substep_phase2<C, true>(A, sp, fz, m_any);
+    if (RR_UNLIKELY(frozen && (fz.r | fz.b))) substep_phase2<C, true>(A, sp, fz, m_any);
     else substep_phase2<C, false>(A, sp, fz, m_any);
     RR_SYNC();
     RR_STAMP(4);
-    if ((fz.r | fz.b) && m_any) { // thaw after the roll phase: the island catches up (move, push, roll), then the full path
+    if (RR_UNLIKELY((fz.r | fz.b) && m_any)) { // thaw after the roll phase: the island catches up (move, push, roll), then the full path
         RR_TRACE("E thaw in phase 2\n");
         const Hit k = fz;
         thaw_island(A, sp, fz, bots_moved);
@@ -1536,13 +1539,13 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
         RR_SYNC();
     }
     RR_TRACE("E phase2 any %d\n", (int)(m_any != 0));
-    if (m_any) { // the reference's loop, from its first pass (nothing has changed since the broad phase above)
+    if (RR_UNLIKELY(m_any)) { // the reference's loop, from its first pass (nothing has changed since the broad phase above)
         bool rr_ok_ = resolve_ball_collisions(A, sp, bots_moved, st, work, hit);
         RR_STAMP(5);
         if (!rr_ok_) { work += 8; undo_naughty_movement(A, sp, balls_moved, bots_moved, st, hit); }
     }
     RR_STAMP(6);
-    if (fz.r) { // still frozen: the island's robots made their move in phase 1; the undo they would have met puts them back
+    if (RR_UNLIKELY(fz.r)) { // still frozen: the island's robots made their move in phase 1; the undo they would have met puts them back
         RR_FOR_LANES(l) {
             if (l < C::NR && ((fz.r >> l) & 1u)) robot_undo_lane(A, sp, l);
         }
@@ -2000,7 +2003,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     using R = typename C::Real;
     int st = 0;
     // raw mode raises when stepping a finished game (:261-262); with auto_reset the call resets instead
-    if ((sp.time_limit ? (A.i.step >= sp.game_len) : (A.i.step > sp.game_len)) || A.i.fault) {
+    if (RR_UNLIKELY((sp.time_limit ? (A.i.step >= sp.game_len) : (A.i.step > sp.game_len)) || A.i.fault)) {
         if (sp.auto_reset) {
             reset_arena(A, sp, arena_gid, (uint64_t)(uint32_t)(A.i.episode + 1), st);
             st |= ST_WAS_RESET;
@@ -2078,7 +2081,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
         // An expensive sub-step: has the arena, or the island that made it expensive, stopped changing?  (The snapshot
         // costs a round trip to the arena's HBM record, so it is only taken when a whole-arena fixed point is possible --
         // no robot moved -- or when the sub-step exhausted the resolve loop.)
-        if (o.snap() && f + 1 < RR_NUM_SUBSTEPS && ((C::NR > 1 && work >= 12) || (work >= 3 && robots_unmoved(A)))) {
+        if (RR_UNLIKELY(o.snap() && f + 1 < RR_NUM_SUBSTEPS && work >= 3 && ((C::NR > 1 && work >= 12) || robots_unmoved(A)))) {
             uint32_t chg_r, chg_re, chg_b;
             bool ax_diff;
             const bool have = snap_at == f - 1;
