@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RR_ABI_VERSION 2
+#define RR_ABI_VERSION 3
 
 /* per-arena status bits; each mirrors one exception site of the reference */
 #define RR_STATUS_BOT_RESOLVE_FAIL 1   /* RR_EnvBase.py:313  "UNABLE TO RESOLVE BOT/BOT COLLISIONS"   */
@@ -158,6 +158,20 @@ int rr_observe_kind_f64(rr_env *env, int32_t kind, int32_t team, int32_t robot_i
  * RR_Robot.py:116-117, RR_Ball.py:60-61) so that observer kind 4 can report it; the call itself (and rr_reset) seeds the
  * copies from the current poses (the reference holds the stale pre-placement pose until the first step). */
 int rr_track_prior_step(rr_env *env, int32_t on, void *stream);
+
+/* Opt-in goal scoring -- an EXTENSION: on the reference's live path the goals never score (Goal.track_balls / update_score are
+ * only reached from the never-called GameEnv.__old_step, RR_EnvBase.py:458-520; RR_Goal.py:80 calls a property as a function),
+ * so there is no reference behaviour to match; this is the mechanism of RR_Goal.py:54-91 + the commented block at
+ * RR_EnvBase.py:494-512 made to work as SURVEY 8(f)-3 words the intent: a ball inside a goal triangle for 150 consecutive steps
+ * is consumed (out of play from then on: parked at x <= -1000), +-500 points (happy team +500 for a positive ball in the happy
+ * goal / a negative one in the grumpy goal, the grumpy team the opposite), 3 negative balls destroy a goal, and a destroyed goal
+ * or an empty field ends the episode (done = 1, status bits below; BaseDestruction pays when it is in the keeper program).
+ * rr_goal_scores: Goal.get_score() of (happy, grumpy) goal per arena, int32 [N,2]; all zero while the mode is off. */
+#define RR_STATUS_GOAL_H_DESTROYED 2048
+#define RR_STATUS_GOAL_G_DESTROYED 4096
+#define RR_STATUS_NO_BALLS 8192
+int rr_set_goal_scoring(rr_env *env, int32_t on, void *stream);
+int rr_goal_scores(rr_env *env, int32_t *scores, void *stream);
 
 /* Logging: return/length of the last finished episode and the number of finished episodes per arena
  * (the caller accumulates `score` the same way, Training_DQN_pytorch.py:345-346). */

@@ -44,6 +44,8 @@ SYMBOLS = {
     "rr_observe_kind": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32, _vp]),
     "rr_observe_kind_f64": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32, _vp]),
     "rr_track_prior_step": (C.c_int, [_vp, C.c_int32, _vp]),
+    "rr_set_goal_scoring": (C.c_int, [_vp, C.c_int32, _vp]),
+    "rr_goal_scores": (C.c_int, [_vp, _vp, _vp]),
     "rr_set_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "rr_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "rr_set_poses": (C.c_int, [_vp, _vp, _vp, _vp]),

@@ -118,6 +118,85 @@ RR_HD void extras_end(const Rec<C> &q, const SimParams<typename C::Real> &sp, co
     if (status && st) *status |= st;
 }
 
+// ---- opt-in goal scoring.  On the reference's live path the goals never score: Goal.track_balls / update_score are only
+// called from GameEnv.__old_step (RR_EnvBase.py:458-520, never called), update_score itself calls the property `is_positive`
+// as a function (RR_Goal.py:80) and the code that consumed the balls is commented out (:494-512).  This is that mechanism made
+// to work, as SURVEY 8(f)-3 words the intent -- there is no reference behaviour to be equal to:
+//   * a ball whose centre stays inside a goal triangle (RightTriangle.contains_point, RR_Goal.py:71-72) for
+//     TIME_BALL_IN_GOAL_STEPS = 150 consecutive steps (RR_Constants.py:27-28; the dctBallsPrior / dctBallsCurrent hand-over of
+//     RR_Goal.py:54-85 keeps the step of entry) is consumed by that goal (`sprBall.kill()`): out of play from then on (parked,
+//     see ball_in_play);
+//   * it scores POINTS_BALL_SCORED = 500 for the happy team when a positive ball lands in the happy goal or a negative one in the
+//     grumpy goal, -500 otherwise; the grumpy team gets the opposite (the commented block at :494-512);
+//   * Goal.get_score = 500 x (positive - negative balls it consumed); a goal with MAX_NEG_BALLS = 3 negative balls is destroyed
+//     (RR_Goal.py:87-91); game_is_done also ends the game when a goal is destroyed or no ball is left (RR_EnvBase.py:555-559);
+//   * BaseDestruction (RR_ScoreKeepers.py:99-109), when it is in the keeper stack, pays POINTS_GOAL_DESTROYED on that step.
+// Per-arena bookkeeping `gs` (int32): [0] steps since reset (Goal.lngFrameCount), [1 + g NB + b] the step at which ball b's
+// current stay in goal g began (-1: not inside), [1 + 2 NB + g] / [3 + 2 NB + g] bit masks of the positive / negative balls
+// goal g has consumed (g = 0 happy, 1 grumpy).
+template <class C> constexpr int gs_stride() { return 1 + 2 * C::NB + 4; }
+template <class C> RR_HD void goal_state_clear(int32_t *gs) {
+    gs[0] = 0;
+    for (int k = 0; k < 2 * C::NB; k++) gs[1 + k] = -1;
+    for (int k = 0; k < 4; k++) gs[1 + 2 * C::NB + k] = 0;
+}
+RR_HD int popcount8(int32_t m) { int n = 0; for (int k = 0; k < 16; k++) n += (m >> k) & 1; return n; }
+// rec / irec: the arena's HBM record (mutable: a consumed ball is parked, the episode bookkeeping follows an early end)
+template <class C, typename O>
+RR_HD void goal_step(typename C::Real *rec, int32_t *irec, const SimParams<typename C::Real> &sp, int32_t *gs, bool base_destruction,
+                     O *reward, O *reward_g, uint8_t *done, int32_t *status) {
+    using R = typename C::Real;
+    constexpr int NR = C::NR, NB = C::NB, BALLS = 10 * NR, ACC = 10 * NR + 8 * NB, I0 = 3 * NR; // irec: step episode ep_len ep_count last_len fault
+    int st = *status;
+    if (st & ST_WAS_RESET) { goal_state_clear<C>(gs); return; } // Goal.on_reset (RR_Goal.py:47-52)
+    if (st & ST_STEP_AFTER_DONE) return;
+    const int frame = ++gs[0];
+    R delta = (R)0;
+    int alive = 0, dummy = 0;
+    for (int g = 0; g < 2; g++)
+        for (int b = 0; b < NB; b++) {
+            const bool in_play = rec[BALLS + b] > (R)-900;
+            V2<R> c = { rec[BALLS + b], rec[BALLS + NB + b] };
+            const bool in = in_play && goal_contains<R>(g == 0, sp.W, sp.H, c, dummy);
+            int since = gs[1 + g * NB + b];
+            if (in) {
+                if (since >= 0 && frame - since >= 150) { // consumed
+                    const bool pos = b < C::NBP;
+                    gs[1 + 2 * NB + (pos ? 0 : 2) + g] |= 1 << b;
+                    delta += ((g == 0) == pos) ? (R)500 : (R)-500;
+                    const R x = park_x<R>(b), y = park_y<R>();
+                    rec[BALLS + b] = x; rec[BALLS + NB + b] = y;
+                    rec[BALLS + 2 * NB + b] = x - (R)7; rec[BALLS + 3 * NB + b] = x + (R)7;
+                    rec[BALLS + 4 * NB + b] = y - (R)7; rec[BALLS + 5 * NB + b] = y + (R)7;
+                    rec[BALLS + 6 * NB + b] = (R)0; rec[BALLS + 7 * NB + b] = (R)0;
+                    since = -1;
+                } else if (since < 0) since = frame;
+            } else since = -1;
+            gs[1 + g * NB + b] = since;
+        }
+    for (int b = 0; b < NB; b++) alive += rec[BALLS + b] > (R)-900 ? 1 : 0;
+    const bool dh = popcount8(gs[1 + 2 * NB + 2]) >= 3, dg = popcount8(gs[1 + 2 * NB + 3]) >= 3;
+    R rh = delta, rg = -delta;
+    if (base_destruction && (dh || dg)) { // (the reference pays the HAPPY team in both branches: kept)
+        const R P = (R)(500 + 200000) * (R)NB; // POINTS_GOAL_DESTROYED, RR_Constants.py:48
+        rh += P; rg -= P;
+    }
+    if (rh != (R)0 || rg != (R)0) {
+        *reward = (O)((R)*reward + rh);
+        if (reward_g) *reward_g = (O)((R)*reward_g + rg);
+        rec[ACC + 0] += rh; rec[ACC + 1] += rg;
+        if (*done) { rec[ACC + 2] = rec[ACC + 0]; rec[ACC + 3] = rec[ACC + 1]; }
+    }
+    st |= (dh ? ST_GOAL_H_DESTROYED : 0) | (dg ? ST_GOAL_G_DESTROYED : 0) | (alive == 0 ? ST_NO_BALLS : 0);
+    if ((dh || dg || alive == 0) && !*done) { // game_is_done (RR_EnvBase.py:555-559): the episode ends here
+        *done = 1;
+        irec[I0 + 5] = 1; // over: a later call re-places the arena (auto_reset) or flags STEP_AFTER_DONE
+        irec[I0 + 4] = irec[I0 + 2]; irec[I0 + 3] += 1;
+        rec[ACC + 2] = rec[ACC + 0]; rec[ACC + 3] = rec[ACC + 1];
+    }
+    *status = st;
+}
+
 // ---- serial two_way_lidar_rect (RR_TrashyPhysics.py:365-391) over the other robots + the walls
 template <class C>
 RR_HD void lidar_serial(const Rec<C> &q, const SimParams<typename C::Real> &sp, int ridx, V2<typename C::Real> a,

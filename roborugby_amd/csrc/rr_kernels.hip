@@ -372,6 +372,28 @@ __global__ void k_extras_end(SimParams<typename C::Real> sp, typename C::Real *r
     rec[ACC + 0] += rh; rec[ACC + 1] += rg;
     if (done[a]) { rec[ACC + 2] = rec[ACC + 0]; rec[ACC + 3] = rec[ACC + 1]; }
 }
+// opt-in goal scoring (rr_extras.hpp: goal_step): thread per arena, after k_step (and k_extras_end)
+template <class C, typename O>
+__global__ void k_goal(SimParams<typename C::Real> sp, typename C::Real *recs, int32_t *irecs, int n, int32_t *gs, int base_destruction,
+                       O *reward, O *reward_g, uint8_t *done, int32_t *status) {
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    goal_step<C, O>(recs + (size_t)a * Arena<C>::P_STRIDE, irecs + (size_t)a * Arena<C>::I_STRIDE, sp, gs + (size_t)a * gs_stride<C>(),
+                    base_destruction != 0, reward + a, reward_g ? reward_g + a : nullptr, done + a, status + a);
+}
+template <class C>
+__global__ void k_goal_clear(int n, int32_t *gs, const uint8_t *mask) {
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n || (mask && !mask[a])) return;
+    goal_state_clear<C>(gs + (size_t)a * gs_stride<C>());
+}
+template <class C>
+__global__ void k_goal_scores(int n, const int32_t *gs, int32_t *scores) { // Goal.get_score (RR_Goal.py:87-88) of the happy / grumpy goal
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    const int32_t *g = gs + (size_t)a * gs_stride<C>() + 1 + 2 * C::NB;
+    for (int k = 0; k < 2; k++) scores[2 * a + k] = 500 * (popcount8(g[k]) - popcount8(g[2 + k]));
+}
 template <class C, typename O>
 __global__ void k_observe_kind(SimParams<typename C::Real> sp, const typename C::Real *recs, int n, int kind, int team, int ridx,
                                int bidx, O *obs, int dim, const typename C::Real *xs) {
@@ -412,6 +434,7 @@ struct rr_env {
     Program prog;        // reward keepers in execution order
     bool custom_prog;    // != SimpleDuel3's {Naughty, Chase, PushPos}
     bool track_prior;    // keep the on_step_begin snapshot up to date for AllCoords_WithPrior (rr_track_prior_step)
+    int32_t *gs;         // goal bookkeeping of the opt-in goal-scoring mode (null: off)
     void *xs;            // on_step_begin snapshot for the side kernels (lazy)
     int32_t *status_buf; // internal status when the caller passes none but the side kernels need it (lazy)
     uint32_t *order;     // slowest-first dispatch order of the arena groups (null: index order)
@@ -494,7 +517,7 @@ int rr_create(const rr_config *cfg, rr_env **out) {
     e->kind = shape + 2 * (cfg->dtype == RR_DTYPE_F32 ? 1 : 0);
     e->vw = 0;
     e->prog.n = 3; e->prog.id[0] = KEEPER_NAUGHTY; e->prog.id[1] = KEEPER_CHASE; e->prog.id[2] = KEEPER_PUSHPOS;
-    e->custom_prog = false; e->track_prior = false; e->xs = nullptr; e->status_buf = nullptr;
+    e->custom_prog = false; e->track_prior = false; e->xs = nullptr; e->status_buf = nullptr; e->gs = nullptr;
     const char *want = getenv("RR_VW");
     const int want_vw = want ? atoi(want) : 0;
 #define X(kind_, a, b, c, d, R_, vw_) \
@@ -574,6 +597,7 @@ int rr_destroy(rr_env *e) {
     if (e->snap) (void)hipFree(e->snap);
     if (e->isnap) (void)hipFree(e->isnap);
     if (e->xs) (void)hipFree(e->xs);
+    if (e->gs) (void)hipFree(e->gs);
     if (e->status_buf) (void)hipFree(e->status_buf);
     if (e->order) (void)hipFree(e->order);
     if (e->cost) (void)hipFree(e->cost);
@@ -591,6 +615,7 @@ int rr_reset(rr_env *e, const uint8_t *mask, float *obs, float *obs_g, void *str
                            (RR *)e->recs, e->irecs, n, mask, 0, obs, obs_g);
         if (e->track_prior && e->xs) // a re-placed arena has no prior step yet: its copies restart from the new poses
             hipLaunchKernelGGL((k_extras_begin<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const RR *)e->recs, n, (RR *)e->xs, mask);
+        if (e->gs) hipLaunchKernelGGL((k_goal_clear<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, n, e->gs, mask); // Goal.on_reset
         return 0;
     });
     if (rc) return rc;
@@ -615,7 +640,7 @@ static int step_impl(rr_env *e, const int32_t *actions, const float *thrust, int
     const int n = e->cfg.num_envs;
     DeviceGuard guard(e->cfg.device);
     hipStream_t s = (hipStream_t)stream;
-    if ((e->custom_prog || e->track_prior) && !status) status = e->status_buf; // the side kernels need the NaughtyBots / WAS_RESET bits
+    if ((e->custom_prog || e->track_prior || e->gs) && !status) status = e->status_buf; // the side kernels need the NaughtyBots / WAS_RESET bits
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
         if constexpr (std::is_same<O, double>::value && !std::is_same<RR, double>::value) {
@@ -638,6 +663,12 @@ static int step_impl(rr_env *e, const int32_t *actions, const float *thrust, int
                 hipLaunchKernelGGL((k_extras_end<CC, O>), dim3((n + 127) / 128), dim3(128), 0, s, params_of<RR>(e),
                                    (RR *)e->recs, n, (RR *)e->xs, e->prog, e->custom_prog ? 1 : 0, reward, reward_g, status,
                                    (const uint8_t *)done);
+            if (e->gs) {
+                int bd = 0;
+                for (int k = 0; k < e->prog.n; k++) bd |= e->prog.id[k] == KEEPER_BASEDESTRUCTION;
+                hipLaunchKernelGGL((k_goal<CC, O>), dim3((n + 127) / 128), dim3(128), 0, s, params_of<RR>(e), (RR *)e->recs, e->irecs, n,
+                                   e->gs, bd, reward, reward_g, done, status);
+            }
             return 0;
         }
     });
@@ -656,8 +687,8 @@ int rr_rollout(rr_env *e, const int32_t *actions, int32_t na, int32_t nsteps, in
                uint8_t *done, float *obs_g, float *reward_g, int32_t *status, void *stream) {
     if (int rc = check_step_args(e, actions, na, obs, reward, done)) return rc;
     if (nsteps < 1 || nsteps > 4096) return fail(-1, "rr_rollout: nsteps must be in 1..4096");
-    if (e->custom_prog || e->track_prior)
-        return fail(-1, "rr_rollout: the side kernels of a custom reward program / prior-step tracking bracket single steps; use rr_step");
+    if (e->custom_prog || e->track_prior || e->gs)
+        return fail(-1, "rr_rollout: the side kernels of a custom reward program / prior-step tracking / goal scoring bracket single steps; use rr_step");
     return step_impl<float>(e, actions, nullptr, na, obs, reward, done, obs_g, reward_g, status, stream, (int)nsteps, repeat != 0);
 }
 int rr_step_thrust(rr_env *e, const float *thrust, int32_t nk, float *obs, float *reward, uint8_t *done, float *obs_g,
@@ -693,6 +724,43 @@ int rr_set_reward_program(rr_env *e, const int32_t *ids, int32_t n) {
         if (int rc = ensure_snapshot_buffer(e)) return rc;
         if (!e->status_buf) HIP_TRY(hipMalloc((void **)&e->status_buf, sizeof(int32_t) * (size_t)e->cfg.num_envs));
     }
+    return 0;
+}
+
+int rr_set_goal_scoring(rr_env *e, int32_t on, void *stream) {
+    if (!e) return fail(-1, "rr_set_goal_scoring: null handle");
+    DeviceGuard guard(e->cfg.device);
+    if (!on) {
+        if (e->gs) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); (void)hipFree(e->gs); e->gs = nullptr; }
+        return 0;
+    }
+    const int n = e->cfg.num_envs;
+    if (!e->status_buf) HIP_TRY(hipMalloc((void **)&e->status_buf, sizeof(int32_t) * (size_t)n));
+    int rc = dispatch(e, [&](auto c) {
+        using CC = decltype(c);
+        if (!e->gs && hipMalloc((void **)&e->gs, sizeof(int32_t) * (size_t)gs_stride<CC>() * (size_t)n) != hipSuccess) {
+            e->gs = nullptr;
+            return fail(-3, "rr_set_goal_scoring: out of device memory");
+        }
+        hipLaunchKernelGGL((k_goal_clear<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, n, e->gs, (const uint8_t *)nullptr);
+        return 0;
+    });
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int rr_goal_scores(rr_env *e, int32_t *scores, void *stream) {
+    if (!e || !scores) return fail(-1, "rr_goal_scores: null argument");
+    const int n = e->cfg.num_envs;
+    DeviceGuard guard(e->cfg.device);
+    if (!e->gs) { HIP_TRY(hipMemsetAsync(scores, 0, sizeof(int32_t) * 2 * (size_t)n, (hipStream_t)stream)); return 0; } // the live reference: identically 0
+    int rc = dispatch(e, [&](auto c) {
+        using CC = decltype(c);
+        hipLaunchKernelGGL((k_goal_scores<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, n, (const int32_t *)e->gs, scores);
+        return 0;
+    });
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -834,6 +902,7 @@ static int set_poses_impl(rr_env *e, const uint8_t *mask, const double *rxyr, co
                            (RR *)e->recs, e->irecs, n, rxyr, bxyv, mask, obs, obs_g);
         if (e->track_prior && e->xs) // like rr_reset: a re-placed arena has no prior step yet
             hipLaunchKernelGGL((k_extras_begin<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const RR *)e->recs, n, (RR *)e->xs, mask);
+        if (e->gs) hipLaunchKernelGGL((k_goal_clear<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, n, e->gs, mask);
         return 0;
     });
     if (rc) return rc;

@@ -136,7 +136,8 @@ __device__ __forceinline__ double lane_xor1(double v) {
 enum : int {
     ST_BOT_RESOLVE_FAIL = 1, ST_BOT_STUCK = 2, ST_UNDO_MOVE_FAIL = 4, ST_UNDO_FAIL = 8, ST_SAME_SPOT = 16,
     ST_DIV0 = 32, ST_STEP_AFTER_DONE = 64, ST_BAD_ACTION = 128, ST_UNDO_WARN = 256, ST_RESET_GAVE_UP = 512,
-    ST_WAS_RESET = 1024
+    ST_WAS_RESET = 1024,
+    ST_GOAL_H_DESTROYED = 2048, ST_GOAL_G_DESTROYED = 4096, ST_NO_BALLS = 8192 // opt-in goal scoring (rr_extras.hpp: goal_step)
 };
 
 // ------------------------------------------------------------------------------------------------ math
@@ -851,6 +852,14 @@ template <class C> RR_HD uint64_t detect_ball_pairs(Arena<C> &A) {
     }
     return mask;
 }
+// A ball whose centre sits at x <= -900 is OUT OF PLAY: it touches nothing, walls included, and earns no ChasePosBall reward.
+// The reference itself parks sprites "off map" at -1000 while it re-places them (RR_EnvBase.py:183-184); the opt-in goal-scoring
+// mode (rr_extras.hpp: goal_step) parks a ball that a goal has consumed -- the reference's `sprBall.kill()` -- at
+// (-1000 - 40 b, -1000) with zero velocity.  Far from everything, so every pair test is negative by itself; only the wall
+// test and the reward need to know.
+template <typename R> RR_HD R park_x(int b) { return (R)-1000 - (R)40 * (R)b; }
+template <typename R> RR_HD R park_y() { return (R)-1000; }
+template <class C> RR_HD bool ball_in_play(const Arena<C> &A, int b) { return A.p.bcx[b] > (typename C::Real)-900; }
 // collided_wall on the int-truncated rect (RR_TrashyPhysics.py:76-85, RR_Ball.py:8-15)
 template <class C> RR_HD bool ball_collided_wall(const Arena<C> &A, const SimParams<typename C::Real> &sp, int b) {
     // pygame.Rect holds C ints: truncation toward zero, which is what a float -> int32 conversion does (one instruction; a
@@ -862,7 +871,7 @@ template <class C> RR_HD bool ball_collided_wall(const Arena<C> &A, const SimPar
 template <class C> RR_HD uint32_t detect_ball_wall(const Arena<C> &A, const SimParams<typename C::Real> &sp) {
     uint64_t m = 0;
     RR_FOR_LANES(l) {
-        bool hit = (l < C::NB) && ball_collided_wall(A, sp, l);
+        bool hit = (l < C::NB) && ball_in_play(A, l < C::NB ? l : 0) && ball_collided_wall(A, sp, l);
         RR_VOTE(m, l, hit);
     }
     return (uint32_t)m;
@@ -1426,7 +1435,7 @@ RR_HD void substep_phase2(Arena<C> &A, const SimParams<typename C::Real> &sp, co
                     c = c | ball_near_robot(A, l, r);
                 }
             }
-            c = c | ball_collided_wall(A, sp, l);
+            c = c | (ball_in_play(A, l) & ball_collided_wall(A, sp, l));
         }
         RR_VOTE(m_any, l, c);
     }
@@ -2119,7 +2128,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
                 const int r = t / C::NBP, b = t % C::NBP;
                 V2<R> rc = { A.p.rcx[r], A.p.rcy[r] }, pc = { A.psx[r], A.psy[r] }, bc = { A.p.bcx[b], A.p.bcy[b] };
                 R now = dist<R>(rc, bc), prior = dist<R>(pc, bc);
-                (&A.u.lidar[0][0])[C::NBP + t] = (prior - now) * sp.mult_robot;
+                (&A.u.lidar[0][0])[C::NBP + t] = ball_in_play(A, b) ? (prior - now) * sp.mult_robot : (R)0; // (a consumed ball: no term)
             }
             if (t < C::NBP) { V2<R> o0 = { (R)0, (R)0 }, c = { A.p.bcx[t], A.p.bcy[t] }; (&A.u.lidar[0][0])[t] = dist<R>(o0, c); }
         }

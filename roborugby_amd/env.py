@@ -29,6 +29,7 @@ STATUS_BITS = {
     128: "action outside Direction 0..7",                 # KeyError at RR_EnvBase.py:606
 }
 STATUS_WARN, STATUS_RESET_GAVE_UP, STATUS_WAS_RESET = 256, 512, 1024
+STATUS_GOAL_H_DESTROYED, STATUS_GOAL_G_DESTROYED, STATUS_NO_BALLS = 2048, 4096, 8192  # opt-in goal scoring only
 STATUS_FLAG_MASK, STATUS_NAUGHTY_SHIFT = 0xFFFF, 16  # info.status: flags in bits 0-15, NaughtyBots' robots in bits 16+
 
 # reward mixins of RR_ScoreKeepers.py (ids of the C-ABI's keeper program) and observer mixins of RR_Observers.py
@@ -93,7 +94,8 @@ class BatchedRoboRugbyEnv:
 
     def __init__(self, num_envs, preset="T", device=None, seed=0, time_limit=True, auto_reset=True, dtype="f64",
                  arena_offset=0, env_id="RoboRugbySimpleDuel-v3", reset_on_fault=None, action_mode="discrete",
-                 rewards=SIMPLE_DUEL3_REWARDS, observer="SingleBall_6wayLidar_v2", lst_starting_config=None):
+                 rewards=SIMPLE_DUEL3_REWARDS, observer="SingleBall_6wayLidar_v2", lst_starting_config=None,
+                 goal_scoring=False):
         self.preset = PRESETS[preset] if isinstance(preset, str) else preset
         assert isinstance(self.preset, Preset)
         if not torch.cuda.is_available():
@@ -133,6 +135,13 @@ class BatchedRoboRugbyEnv:
         prog = np.asarray(keeper_exec_order(self.rewards), np.int32)
         _lib.check(self._lib.rr_set_reward_program(self._h, prog.ctypes.data_as(C.c_void_p), len(prog)),
                    "rr_set_reward_program")
+        # Opt-in goal scoring -- an EXTENSION: the reference's goals never score on its live path
+        # (RR_Goal.py:58-91 is only reached from the never-called __old_step and is broken), so this has no reference behaviour
+        # to match.  A ball inside a goal triangle for 150 consecutive steps is consumed (out of play), +-500 points, three
+        # negative balls destroy a goal, a destroyed goal / an empty field ends the episode (include/roborugby_amd.h).
+        self.goal_scoring = bool(goal_scoring)
+        if self.goal_scoring:
+            _lib.check(self._lib.rr_set_goal_scoring(self._h, 1, self._stream()), "rr_set_goal_scoring")
         m = max(p.arena_w, p.arena_h, 360)  # RR_Observers.py:30-37
         self.observation_space = Box(-m, m, (self.obs_dim,), np.float32)
         # GameEnv_Simple: Discrete(8) (RR_EnvBase.py:610); bare GameEnv: Box(-1, 1, (2*happy robots,)) (RR_EnvBase.py:118-123),
@@ -375,8 +384,11 @@ class BatchedRoboRugbyEnv:
 
     def goal_scores(self):
         """Goal.get_score() of (happy, grumpy) goal (RR_Goal.py:87-88): identically 0 on the live path -- the reference
-        never feeds its goal bookkeeping, so `done` is purely the step counter."""
-        return torch.zeros((self.num_envs, 2), dtype=torch.int32, device=self.device)
+        never feeds its goal bookkeeping, so `done` is purely the step counter -- unless the env was
+        built with goal_scoring=True (the opt-in extension): then 500 x (positive - negative balls the goal has consumed)."""
+        s = self._new((self.num_envs, 2), torch.int32)
+        _lib.check(self._lib.rr_goal_scores(self._h, _ptr(s), self._stream()), "rr_goal_scores")
+        return s
 
     def episode_stats(self):
         """(last finished episode return happy, grumpy, its length, number of finished episodes) per arena."""

@@ -23,6 +23,8 @@ template <class C> struct Emu {
     uint32_t snap[Arena<C>::SNAP_WORDS];
     typename C::Real xs[3 * C::NR + 1 + 2 * C::NB]; // on_step_begin snapshot (always taken here: AllCoords_WithPrior reads it)
     int32_t isnap[2 * C::NR];
+    int goal_scoring;              // opt-in goal scoring (rr_extras.hpp: goal_step)
+    int32_t gs[1 + 2 * C::NB + 4];
 };
 
 template <typename R> static void fill_params(SimParams<R> &sp, double W, double H, int game_len, int game_mode,
@@ -95,6 +97,10 @@ struct Handle { int kind; void *p; };
 
 extern "C" {
 void emu_debug_set_substeps(int k) { g_dbg_substeps = k; }
+void emu_set_goal_scoring(Handle *h, int on) { DISPATCH(h, (e->goal_scoring = on, goal_state_clear<CC>(e->gs))); }
+void emu_goal_scores(Handle *h, int32_t *s2) {
+    DISPATCH(h, { const int32_t *g = e->gs + 1 + 2 * CC::NB; for (int k = 0; k < 2; k++) s2[k] = 500 * (popcount8(g[k]) - popcount8(g[2 + k])); });
+}
 void emu_debug_trace(int on) { g_dbg_trace = on; }
 void emu_debug_memo(int on) { g_dbg_memo = on; }
 // primitives of the kernel source, for unit tests
@@ -151,6 +157,11 @@ template <class CC> static int emu_step_t(Emu<CC> *e, const int32_t *actions, co
         RR rh, rg;
         extras_end<CC, double>(q, e->sp, xs, e->prog, (uint32_t)status >> 16, reward, reward_g, &status, rh, rg);
     }
+    if (e->goal_scoring) { // the arena's LDS image has the record's layout: P, then I
+        bool bd = false;
+        for (int k = 0; k < e->prog.n; k++) bd |= e->prog.id[k] == KEEPER_BASEDESTRUCTION;
+        goal_step<CC, double>(reinterpret_cast<RR *>(&e->A.p), reinterpret_cast<int32_t *>(&e->A.i), e->sp, e->gs, bd, reward, reward_g, done, &status);
+    }
     return status;
 }
 } // extern "C++"
@@ -184,7 +195,7 @@ int emu_observe(Handle *h, int team, int ridx, int bidx, double *obs) {
 }
 int emu_reset(Handle *h, uint64_t arena, uint64_t episode) {
     int st = 0;
-    DISPATCH(h, reset_arena(e->A, e->sp, arena, episode, st));
+    DISPATCH(h, (reset_arena(e->A, e->sp, arena, episode, st), goal_state_clear<CC>(e->gs)));
     return st;
 }
 }

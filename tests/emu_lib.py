@@ -41,6 +41,8 @@ def lib():
         L.emu_reset.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
         L.emu_set_program.argtypes = [C.c_void_p, ip, C.c_int]
         L.emu_observe_kind.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+        L.emu_set_goal_scoring.argtypes = [C.c_void_p, C.c_int]
+        L.emu_goal_scores.argtypes = [C.c_void_p, ip]
         L.emu_py_mod360.restype = C.c_double
         L.emu_py_mod360.argtypes = [C.c_double]
         L.emu_sincos.argtypes = [C.c_double, dp, dp]
@@ -117,6 +119,14 @@ class EmuEnv:
                                    _dp(rew), _dp(rew_g), done.ctypes.data_as(C.POINTER(C.c_uint8)))
         return dict(obs=obs, obs_g=obs_g, reward=float(rew[0]), reward_g=float(rew_g[0]), done=bool(done[0]),
                     status=int(st) & 0xFFFF, naughty=(int(st) >> 16) & 0xFF)
+
+    def set_goal_scoring(self, on=True):
+        lib().emu_set_goal_scoring(self.h, int(on))
+
+    def goal_scores(self):
+        s = np.zeros(2, np.int32)
+        lib().emu_goal_scores(self.h, _ip(s))
+        return s
 
     def observe(self, team=1, robot=-1, ball=-1):
         o = np.zeros(11)

@@ -48,6 +48,8 @@ def lib():
         L.rro_step_thrust.argtypes = [C.c_void_p, dp, C.c_int, dp, dp, dp, dp, u8p, ip]
         L.rro_reset.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
         L.rro_status.argtypes = [C.c_void_p]
+        L.rro_set_goal_scoring.argtypes = [C.c_void_p, C.c_int]
+        L.rro_goal_scores.argtypes = [C.c_void_p, ip]
         L.rro_kat_line_intersection.argtypes = [dp, dp, u8p]
         L.rro_kat_dist_angle.argtypes = [dp, dp]
         L.rro_kat_floatrect.argtypes = [dp, dp, dp]
@@ -154,6 +156,15 @@ class OracleEnv:
     def reset(self, seed, arena, episode):
         lib().rro_reset(self.h, int(seed), int(arena), int(episode))
         return lib().rro_status(self.h)
+
+    def set_goal_scoring(self, on=True):
+        """Opt-in goal scoring: an extension with no reference behaviour behind it (oracle/rr_oracle.c: goal_step)."""
+        lib().rro_set_goal_scoring(self.h, int(on))
+
+    def goal_scores(self):
+        s = np.zeros(2, np.int32)
+        lib().rro_goal_scores(self.h, _ip(s))
+        return s
 
 
 def rollout(preset, n_env, n_steps, seed=0):

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/roborugby_amd.h but not exported"
     assert set(decl) == set(_lib.SYMBOLS), (set(decl) ^ set(_lib.SYMBOLS))
     lib.rr_abi_version.restype = C.c_int
-    assert lib.rr_abi_version() == 2
+    assert lib.rr_abi_version() == 3
 
 
 def test_config_struct_matches_header_layout():
