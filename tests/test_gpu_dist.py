@@ -102,3 +102,28 @@ def test_config4_shape_eight_shards_of_65536_equal_one_batch_of_524288():
         for a, b in zip(part, big):
             b = b[r * n:(r + 1) * n]
             assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0)), r
+
+
+@pytest.mark.timeout(600)
+def test_bench_single_gpu_line_carries_roofline_and_cpu_baseline():
+    """bench.py as the driver runs it at N = 1 (short): ONE JSON line with the contract's keys, the roofline object of the
+    dominant kernel and the cpu_baseline object (the oracle timed on this box's host cores)."""
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3", "--cpu-seconds", "2"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=540, cwd=REPO)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 3 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["algorithmic_bytes_per_env_step"] == 601 and rf["record_bytes_per_env"] == 960
+    # achieved = algorithmic bytes of one launch / the live HIP-event time of that launch
+    assert abs(rf["achieved"] - 601 * 65536 / (rf["kernel_ms"] * 1e-3) / 1e9) / rf["achieved"] < 1e-9
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "env-steps/s" and cb["cores"] >= 1 and cb["value"] > 100 and "sample" in cb
+    assert abs(d["value"] - 65536 * 10 / (d["ms_per_step"] * 10e-3)) / d["value"] < 0.02
