@@ -1216,6 +1216,7 @@ template <class C> RR_HDN void resolve_bot_collisions(Arena<C> &A, const SimPara
 template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t bots_moved, int &st, int &work, Hit &hit) {
     bool naughty = true;
     int count = 0;
+    RR_T0();
     RR_FOR_LANES(l) { if (l < C::NB) ball_exc_update(A, l); } // where the push and the roll have left each ball
     while (naughty) {
         count++;
@@ -1232,8 +1233,10 @@ template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimPar
             naughty = true;
             bounce_balls(A, i, j, st);
         }
+        RR_STAMP(14);
         // caches already built in this sub-step (a hit in the push or in an earlier pass)?  then the cheap variant
         uint32_t br = A.sides_ok ? detect_ball_robot<C, true>(A, sp) : detect_ball_robot<C, false>(A, sp);
+        RR_STAMP(15);
 #pragma unroll 1
         for (uint32_t todo = br; todo; todo &= todo - 1) {
             const int p = low_bit(todo);
@@ -1241,6 +1244,7 @@ template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimPar
             hit.b |= 1u << (p / C::NR); hit.r |= 1u << (p % C::NR);
             bounce_ball_off_bot(A, sp, p % C::NR, p / C::NR, bots_moved, st);
         }
+        RR_STAMP(16);
         uint32_t bw = detect_ball_wall(A, sp);
         if (bw) {
             naughty = true;
@@ -1250,6 +1254,7 @@ template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimPar
             }
             RR_SYNC();
         }
+        RR_STAMP(17);
     }
     RR_TRACE("E resolve done in %d passes\n", count);
     return true;
@@ -1260,6 +1265,7 @@ RR_HDN void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real>
     bool naughty = true;
     int count = 0;
     const int limit = C::NB + C::NR;
+    RR_T0();
     while (naughty) {
         count++;
         if (count > limit) {
@@ -1282,6 +1288,7 @@ RR_HDN void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real>
             nbots |= 1u << (p % C::NR);
         }
         nballs |= detect_ball_wall(A, sp);
+        RR_STAMP(18);
         naughty = (nbots | nballs) != 0;
         hit.r |= nbots; hit.b |= nballs;
         uint32_t ubots = bots_moved & nbots, uballs = balls_moved & nballs;
@@ -1295,6 +1302,7 @@ RR_HDN void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real>
             }
             RR_SYNC();
         }
+        RR_STAMP(19);
         if (naughty && !(ubots | uballs)) {
             // nothing left to undo: every further iteration would find the same contacts and change nothing, so the
             // reference ends the same way -- the raise after NB+NR iterations (GAME_MODE=False) or the warning
@@ -1443,12 +1451,15 @@ RR_HD void substep_phase2(Arena<C> &A, const SimParams<typename C::Real> &sp, co
 // _push_balls over a frozen hit list (RR_EnvBase.py:335-339), ball-major order
 template <class C>
 RR_HD void push_balls(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t br, uint32_t bots_moved, int &st, Hit &hit) {
+    RR_T0();
 #pragma unroll 1
     for (uint32_t todo = br; todo; todo &= todo - 1) {
         const int p = low_bit(todo);
         hit.b |= 1u << (p / C::NR); hit.r |= 1u << (p % C::NR);
         apply_force_to_ball(A, sp, p % C::NR, p / C::NR, bots_moved, st);
+        RR_STAMP(20);
         bounce_ball_off_bot(A, sp, p % C::NR, p / C::NR, bots_moved, st);
+        RR_STAMP(21);
     }
     if (br) { // the pushed balls' force and velocity changed: their roll bound with them
         RR_FOR_LANES(l) { if (l < C::NB) A.reach[l] = ball_reach(A, l); }
@@ -1521,6 +1532,7 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     RR_STAMP(2);
     if (RR_UNLIKELY(m_br)) { // _push_balls (RR_EnvBase.py:335-339): frozen hit list, ball-major order
         uint32_t br = detect_ball_robot<C, false>(A, sp);
+        RR_STAMP(22);
         RR_TRACE("E push mask %08x\n", br);
         push_balls(A, sp, br, bots_moved, st, hit);
     }

@@ -31,8 +31,10 @@ K = 20
 for _ in range(K): step()
 torch.cuda.synchronize(); lib.rr_debug_phase_cycles(buf, 0)
 names = ["(unused)", "hooks + moves + broad", "resolve_bot (if close)", "push (if close)", "roll + broad", "resolve loop (if close)", "undo (if failed)", "(unused)",
-         "step_begin", "(12 substeps total)", "rewards", "obs+out", "load+derive", "store"]
-v = list(buf)[:14]
+         "step_begin", "(12 substeps total)", "rewards", "obs+out", "load+derive", "store",
+         "  resolve: ball-ball detect + bounces", "  resolve: ball-robot detect", "  resolve: bounce_ball_off_bot", "  resolve: wall detect + bounce",
+         "  undo: detections", "  undo: undo lanes", "  push: apply_force_to_ball", "  push: bounce_ball_off_bot", "  push: ball-robot detect (no cache)"]
+v = list(buf)[:23]
 tot = sum(v[i] for i in (8, 9, 10, 11, 12, 13))
 waves = (n // (64 // env.lanes_per_env()) + 63) // 64  # every 64th wavefront is stamped
 print(f"{preset} {mode}: VW={env.lanes_per_env()} s_memtime ticks per wave per step: {tot / K / waves:.0f}")
