@@ -36,7 +36,8 @@ def init_process_group(backend=None):
     dev = local_device_index(local_rank)
     if torch.cuda.is_available():
         torch.cuda.set_device(dev)
-    if world > 1 and not dist.is_initialized():
+    # (RR_DIST_FORCE_INIT=1 builds the group even for a single rank: lets a one-GPU box exercise the RCCL code path itself)
+    if (world > 1 or os.environ.get("RR_DIST_FORCE_INIT")) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or os.environ.get("RR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -60,7 +61,7 @@ def _comm_tensor(t):
 def all_gather_returns(local, async_op=False):
     """All-gathers a per-arena tensor [n_local, ...] into [world*n_local, ...] in global arena order.
     256 KiB per rank at 65,536 fp32 returns; latency-bound, issued off the critical path."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not os.environ.get("RR_DIST_FORCE_INIT")):
         return (local.clone(), None) if async_op else local.clone()
     world = dist.get_world_size()
     src = _comm_tensor(local.contiguous())
@@ -77,7 +78,7 @@ def all_gather_returns(local, async_op=False):
 def _reduce(value, device, op):
     dev = torch.device("cpu") if _backend() == "gloo" else device
     t = torch.tensor([value], dtype=torch.float64, device=dev)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("RR_DIST_FORCE_INIT")):
         dist.all_reduce(t, op=op)
     return float(t.item())
 
@@ -92,7 +93,7 @@ def reduce_sum(value, device):
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("RR_DIST_FORCE_INIT")):
         if _backend() == "nccl":
             dist.barrier(device_ids=[torch.cuda.current_device()])
         else:

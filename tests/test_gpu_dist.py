@@ -127,3 +127,17 @@ def test_bench_single_gpu_line_carries_roofline_and_cpu_baseline():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "env-steps/s" and cb["cores"] >= 1 and cb["value"] > 100 and "sample" in cb
     assert abs(d["value"] - 65536 * 10 / (d["ms_per_step"] * 10e-3)) / d["value"] < 0.02
+
+
+@pytest.mark.timeout(600)
+def test_rccl_backend_itself_on_a_single_rank_group():
+    """The nccl (= RCCL) backend cannot host two ranks on one device, so the two-process test above rides on gloo; this one
+    builds a ONE-rank RCCL group in a fresh process and runs bench.py's collective calls through RCCL proper (device bound to
+    the communicator, all-gather sync / async, reductions, barrier with device_ids)."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               RR_DIST_FORCE_INIT="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RR_DIST_BACKEND", None)
+    p = subprocess.run([sys.executable, os.path.join(REPO, "tests", "dist_child_nccl.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=540)
+    assert p.returncode == 0 and "RCCL single-rank group OK" in p.stdout, p.stdout[-3000:]
+    assert "guessing device" not in p.stdout.lower()
