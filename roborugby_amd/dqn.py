@@ -245,9 +245,15 @@ def evaluate(env, policy, episodes=1):
 def train(num_envs=65536, steps=300, preset="T", device="cuda:0", seed=0, checkpoint=None, resume=None,
           log_every=50, learn=True, mem_size=None, dtype="f64", updates_per_step=4, batch_size=None,
           replay_vector_steps=32, target_sync_vector_steps=64, eps_dec=.999997, eps_end=0.2, eval_every=0,
-          eval_envs=16384, out=None):
+          eval_envs=16384, out=None, overlap_learn=True):
     """The main loop of Training_DQN_pytorch.py:317-377 over a batched env.  Returns a dict of throughput / score /
-    the return curve (greedy policy vs the random policy on a separate evaluation batch, every `eval_every` steps)."""
+    the return curve (greedy policy vs the random policy on a separate evaluation batch, every `eval_every` steps).
+
+    overlap_learn: the k gradient steps that follow a vector step run on a second HIP stream WHILE the simulator steps the
+    next one (under a contact-seeking policy `k_step` is one long launch bound by its slowest arenas and leaves most CUs idle).
+    Stream-ordered, deterministic: choose_action(t) -> [side: learn x k on the replay up to t-1] || [main: env.step(t)] ->
+    store_transition(t) waits for the side stream -> choose_action(t+1).  The updates see the replay one vector step later
+    than in the serial order (same number of updates, same schedules)."""
     import roborugby_amd as rr
     env = rr.make("RoboRugbySimpleDuel-v3", num_envs=num_envs, preset=preset, device=device, seed=seed, dtype=dtype)
     p = env.preset
@@ -282,24 +288,40 @@ def train(num_envs=65536, steps=300, preset="T", device="cuda:0", seed=0, checkp
     t0 = time.perf_counter()
     t_eval = 0.0
     score_sum = torch.zeros(num_envs, device=device)
-    transitions = 0
+    overlap = bool(overlap_learn and learn and torch.device(device).type == "cuda")
+    main_stream = torch.cuda.current_stream(torch.device(device))
+    side = torch.cuda.Stream(device=torch.device(device)) if overlap else None
     for i in range(steps):
         action = agent.choose_action(observation)
         acts = action.view(-1, 1)
         if grumpy:
             action_grumpy = agent.choose_action(obs_grumpy)
+        learned = None
+        if overlap:  # the gradient steps on what the replay holds so far, next to the simulator's step
+            chosen = torch.cuda.Event()
+            chosen.record(main_stream)
+            with torch.cuda.stream(side):
+                side.wait_event(chosen)  # choose_action has read Q_eval
+                for _ in range(updates_per_step):
+                    agent.learn()
+                learned = torch.cuda.Event()
+                learned.record(side)
         observation_, reward, done, info = env.step(acts)
         real = (info.status & 1024) == 0  # a call that only re-placed the arena is not a transition
         score_sum += reward
         if learn:
+            if learned is not None:
+                main_stream.wait_event(learned)  # the sampled rows are read, Q_eval is written: the ring and the net are ours again
             agent.store_transition(observation, action, reward, observation_, done, valid=real)
             if grumpy:
                 agent.store_transition(obs_grumpy, action_grumpy, info.dblGrumpyScore, info.adblGrumpyState, done, valid=real)
-            for _ in range(updates_per_step):
-                agent.learn()
+            if not overlap:
+                for _ in range(updates_per_step):
+                    agent.learn()
         observation = observation_
         obs_grumpy = info.adblGrumpyState
         if log_every and (i + 1) % log_every == 0:
+            torch.cuda.synchronize()
             lr_, _, ll, cnt = env.episode_stats()
             fin = cnt > 0
             avg = float(lr_[fin].mean()) if bool(fin.any()) else float("nan")
@@ -323,7 +345,7 @@ def train(num_envs=65536, steps=300, preset="T", device="cuda:0", seed=0, checkp
     lr_, _, ll, cnt = env.episode_stats()
     res = dict(env_steps_per_sec=num_envs * steps / dt, seconds=dt, num_envs=num_envs, steps=steps,
                learn_calls=agent.updates, updates_per_step=updates_per_step if learn else 0, batch_size=B,
-               samples_per_transition=(updates_per_step * B / (num_envs * n_teams)) if learn else 0.0,
+               samples_per_transition=(updates_per_step * B / (num_envs * n_teams)) if learn else 0.0, overlap_learn=overlap,
                replay_transitions=agent.mem_size, target_update_freq=agent.target_update_freq, target_syncs=agent.target_syncs,
                epsilon=agent.epsilon, eps_dec=eps_dec, eps_end=eps_end, finished_episodes=int(cnt.sum()),
                mean_step_reward=float(score_sum.mean() / steps), preset=preset, dtype=dtype, curve=curve)
@@ -364,10 +386,11 @@ def main():
     ap.add_argument("--eval-envs", type=int, default=16384)
     ap.add_argument("--log-every", type=int, default=50)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--no-overlap", action="store_true", help="gradient steps after the simulator's step instead of next to it")
     a = ap.parse_args()
     res = train(a.num_envs, a.steps, a.preset, a.device, a.seed, a.checkpoint, a.resume, learn=not a.no_learn,
                 updates_per_step=a.updates_per_step, batch_size=a.batch_size, eps_dec=a.eps_dec, eval_every=a.eval_every,
-                eval_envs=a.eval_envs, log_every=a.log_every, out=a.out)
+                eval_envs=a.eval_envs, log_every=a.log_every, out=a.out, overlap_learn=not a.no_overlap)
     print(json.dumps({k: v for k, v in res.items() if k != "curve"}))
 
 

@@ -104,9 +104,13 @@ def test_train_loop_end_to_end_on_gpu(tmp_path):
     from roborugby_amd.dqn import train
     ck = str(tmp_path / "ck.pt")
     res = train(num_envs=4096, steps=12, device="cuda:0", checkpoint=ck, log_every=0)
-    assert res["env_steps_per_sec"] > 1e4 and res["learn_calls"] == 12 * 4
+    # (overlap mode: the k updates of an iteration run next to that iteration's env.step, on the replay as it stood before it,
+    # so the first iteration has nothing to learn from)
+    assert res["env_steps_per_sec"] > 1e4 and res["overlap_learn"] and res["learn_calls"] == (12 - 1) * 4
     res2 = train(num_envs=4096, steps=3, device="cuda:0", resume=ck, log_every=0)
     assert res2["steps"] == 3
+    res3 = train(num_envs=4096, steps=12, device="cuda:0", log_every=0, overlap_learn=False)  # the serial order is still there
+    assert not res3["overlap_learn"] and res3["learn_calls"] == 12 * 4
     with pytest.raises(Exception, match="Game mode"):
         train(num_envs=64, steps=1, preset="G", device="cuda:0", log_every=0)
 
@@ -120,7 +124,7 @@ def test_config5_trains_at_65536_arenas(tmp_path):
     from roborugby_amd.dqn import train
     ck = str(tmp_path / "ck65536.pt")
     res = train(num_envs=65536, steps=40, device="cuda:0", checkpoint=ck, log_every=0, replay_vector_steps=8)
-    assert res["num_envs"] == 65536 and res["learn_calls"] == 40 * 4 and res["batch_size"] == 32768
+    assert res["num_envs"] == 65536 and res["learn_calls"] == (40 - 1) * 4 and res["batch_size"] == 32768
     assert res["replay_transitions"] == 8 * 65536 and res["epsilon"] == 0.2  # 2.6 M transitions: the floor (5.4e5 suffice)
     assert res["target_syncs"] == 0 and res["target_update_freq"] == 64 * 65536
     assert res["env_steps_per_sec"] > 2e6
@@ -148,4 +152,4 @@ def test_config5_learns_to_beat_the_random_policy():
     print(f"random policy {rand:.0f}, greedy after 300 / 600 vector steps {curve[1]['greedy_return']:.0f} / {curve[2]['greedy_return']:.0f}; "
           f"training {res['env_steps_per_sec'] / 1e6:.1f} M env-steps/s, greedy rollout {res['rollout_env_steps_per_sec_greedy_policy'] / 1e6:.1f} M")
     assert abs(rand) < 1000 and best > rand + 1500
-    assert res["epsilon"] == 0.2 and res["learn_calls"] == 2400
+    assert res["epsilon"] == 0.2 and res["learn_calls"] == 599 * 4
