@@ -169,6 +169,7 @@ RR_HD void goal_step(typename C::Real *rec, int32_t *irec, const SimParams<typen
                     rec[BALLS + 2 * NB + b] = x - (R)7; rec[BALLS + 3 * NB + b] = x + (R)7;
                     rec[BALLS + 4 * NB + b] = y - (R)7; rec[BALLS + 5 * NB + b] = y + (R)7;
                     rec[BALLS + 6 * NB + b] = (R)0; rec[BALLS + 7 * NB + b] = (R)0;
+                    irec[I0 + 6] = 0; // a ball left the field: whatever island the step ended with is not carried over (Arena::I::fzp)
                     since = -1;
                 } else if (since < 0) since = frame;
             } else since = -1;

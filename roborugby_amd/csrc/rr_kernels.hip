@@ -266,6 +266,7 @@ __global__ void k_set_state(typename C::Real *recs, int32_t *irecs, int n, const
         for (int f = 0; f < 8; f++) rec[10 * NR + f * NB + b] = (R)balls[((size_t)a * NB + b) * 8 + f];
     irec[3 * NR + 0] = step[a];
     irec[3 * NR + 5] = 0; // fault flag
+    irec[3 * NR + 6] = 0; // no island carried over from the previous step (Arena::I::fzp)
 }
 template <class C>
 __global__ void k_get_state(const typename C::Real *recs, const int32_t *irecs, int n, double *robots, int32_t *ri,
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_set_poses(SimParams<ty
         const double *q = bxyv + ((size_t)arena * C::NB + lane) * 4;
         ball_set_clean_lane(A, lane, (R)q[0], (R)q[1], (R)q[2], (R)q[3]);
     }
-    if (lane == 0) { A.i.step = 0; A.i.ep_len = 0; A.i.fault = 0; A.p.acc[0] = (R)0; A.p.acc[1] = (R)0; }
+    if (lane == 0) { A.i.step = 0; A.i.ep_len = 0; A.i.fault = 0; A.i.fzp = 0; A.p.acc[0] = (R)0; A.p.acc[1] = (R)0; }
     RR_SYNC();
     if (obs || obs_g) {
         int st = 0;

@@ -319,7 +319,7 @@ template <int NRH_, int NRG_, int NBP_, int NBN_, typename Real_, int VW_ = 64> 
     using Real = Real_;
     static_assert(VW == 2 || VW == 4 || VW == 8 || VW == 16 || VW == 32 || VW == 64, "VW must divide the wavefront");
     static_assert(NR >= 1 && NR <= VW && NB >= 1 && NB <= VW, "one lane per entity");
-    static_assert(NB * NR <= 32 && NPB <= 64, "pair masks are 32/64-bit");
+    static_assert(NB * NR <= 32 && NPB <= 64 && NB <= 16 && NR <= 16, "pair masks are 32/64-bit, per-ball masks 16-bit");
 };
 
 template <typename R> struct SimParams {
@@ -351,6 +351,7 @@ template <class C> struct ArenaBody {
     struct I {
         int32_t mc[NR], thl[NR], thr[NR];
         int32_t step, episode, ep_len, ep_count, last_len, fault;
+        int32_t fzp, fexc; // the island that was still frozen when the last step ended (step_arena: "island freeze across steps")
     } i;
     // ---- per-step scratch
     // (rows of 9, not 8: a 16-word row stride would put every robot's row of every arena of a bank group on the same 4 banks)
@@ -361,7 +362,8 @@ template <class C> struct ArenaBody {
     R psx[NR], psy[NR]; // robot centre at step begin (rectDblPriorStep)
     R bfx[NB], bfy[NB], pfx[NB], pfy[NB];
     int32_t bmass[NB];
-    int32_t bbm[NB], brc[NB]; // per-ball hit / close bit masks of the contact sweeps (one lane per ball writes its own)
+    uint16_t bbm[NB], brc[NB]; // per-ball hit / close bit masks of the contact sweeps (one lane per ball writes its own; 16 bits:
+                               // NB <= 11, NR <= 8 -- the G slice has no byte to spare, see wm below)
     R exc[NB];                // how far (L1) the contact responses of this sub-step have carried the ball from its frame-begin centre
     R reach[NB];              // 14.04 + the most the ball can travel in this sub-step's roll: the ball-ball bound of the fused roll phase
     int32_t sides_ok; // sm/sc match the current robot poses (rebuilt lazily by the first phase that needs them)
@@ -378,7 +380,7 @@ template <class C> struct ArenaBody {
     static constexpr int P_REALS = (int)(sizeof(P) / sizeof(R));
     static constexpr int I_INTS = (int)(sizeof(I) / sizeof(int32_t));
     // HBM record of one arena: the P reals, the I ints right behind them, padded to a 64-B multiple (so that the lane-strided
-    // runs of the arenas sharing a wavefront start on request boundaries).  G/fp64: 108 reals + 18 ints = 936 -> 960 B.
+    // runs of the arenas sharing a wavefront start on request boundaries).  G/fp64: 108 reals + 20 ints = 944 -> 960 B.
     static constexpr int WR = (int)(sizeof(R) / 4);                       // 32-bit words per real
     static constexpr int P_ALIGN = 64 / (int)sizeof(R);
     static constexpr int P_STRIDE = (P_REALS + (I_INTS + WR - 1) / WR + P_ALIGN - 1) / P_ALIGN * P_ALIGN; // reals per record
@@ -757,7 +759,7 @@ template <class C, bool CACHED> RR_HD uint32_t detect_ball_robot(Arena<C> &A, co
         if (l < C::NB) {
             int msk = 0;
             for (int r = 0; r < C::NR; r++) msk |= ball_near_robot(A, l, r) ? (1 << r) : 0;
-            A.brc[l] = msk;
+            A.brc[l] = (uint16_t)msk;
             c = msk != 0;
         }
         RR_VOTE(anyc, l, c);
@@ -836,7 +838,7 @@ template <class C> RR_HD uint64_t detect_ball_pairs(Arena<C> &A) {
                 R dx = b.x - a.x, dy = b.y - a.y;
                 if (j > l && dx * dx + dy * dy <= (R)197) msk |= (dist<R>(a, b) <= (R)14) ? (1 << j) : 0;
             }
-            A.bbm[l] = msk;
+            A.bbm[l] = (uint16_t)msk;
             h = msk != 0;
         }
         RR_VOTE(anyh, l, h);
@@ -880,7 +882,6 @@ template <class C> RR_HD uint32_t detect_ball_wall(const Arena<C> &A, const SimP
 // excursion bookkeeping for the island freeze (see substep): called after every position write of the contact paths
 template <class C> RR_HD void ball_exc_update(Arena<C> &A, int b) {
     using R = typename C::Real;
-    if (C::NR < 2) return; // no islands in a one-robot arena
     const R e = m_abs(A.p.bcx[b] - A.pfx[b]) + m_abs(A.p.bcy[b] - A.pfy[b]);
     if (e > A.exc[b]) A.exc[b] = e;
 }
@@ -1521,7 +1522,7 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     RR_SYNC();
     RR_STAMP(1);
     if (RR_UNLIKELY((fz.r | fz.b) && (m_rr | m_br | m_wm))) { // thaw before anything depended on the island
-        RR_TRACE("E thaw in phase 1\n");
+        RR_TRACE("E thaw in phase 1: rr %llx br %llx wm %llx\n", (unsigned long long)m_rr, (unsigned long long)m_br, (unsigned long long)m_wm);
         thaw_island(A, sp, fz, bots_moved);
         m_rr = 1; m_br = 1;
     }
@@ -1866,7 +1867,7 @@ RR_HDN void reset_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint
     RR_FOR_LANES(l) {
         if (l < C::NR) robot_set_clean_lane(A, sp, l, A.p.rcx[l], A.p.rcy[l], l < C::NRH ? (R)90 : (R)-90);
         if (l < C::NB) { A.p.bvx[l] = (R)0; A.p.bvy[l] = (R)0; }
-        if (l == 0) { A.i.step = 0; A.i.episode = (int32_t)episode; A.i.ep_len = 0; A.i.fault = 0; A.p.acc[0] = (R)0; A.p.acc[1] = (R)0; }
+        if (l == 0) { A.i.step = 0; A.i.episode = (int32_t)episode; A.i.ep_len = 0; A.i.fault = 0; A.i.fzp = 0; A.p.acc[0] = (R)0; A.p.acc[1] = (R)0; }
     }
     RR_SYNC();
     // robots not yet placed still block at their old pose (RR_EnvBase.py:157-158 writes sprite attrs only)
@@ -2017,6 +2018,21 @@ RR_HD void snapshot_compare_update(const Arena<C> &A, uint32_t *snap, int32_t *i
     chg_r = cr; chg_re = cre; chg_b = cb; ax_diff = any_ax != 0;
 }
 
+// Island freeze ACROSS steps.  A stuck island usually stays stuck for many steps (a robot driving a ball into a wall keeps
+// driving), and within a step it costs two expensive sub-steps to find it again (snapshot, compare).  Nothing between two
+// steps touches an island except its robots' new thrust -- the step-begin hooks only take copies for the rewards -- so an
+// island that is still frozen when a step ends, whose robots are given the same thrust again, is the same fixed point of the
+// same map: the next step starts with it frozen.  What the frozen sub-steps need travels in two ints of the record
+// (Arena::I::fzp, fexc): the island (robots 4 bits, balls 8), how each of its robots' moves met the walls (wm, 2 bits each),
+// the NaughtyBots members and status bits one computed sub-step of the island produces (they are per step: a frozen
+// sub-step ORs them in), and an upper bound of its balls' excursions.  Everything that rewrites an arena from outside
+// (reset, rr_set_state, rr_set_poses, the goal-scoring side kernel) clears the word.  Same results with RR_NO_MEMO=1.
+RR_HD uint32_t fz_pack_bits(uint32_t naughty, int st) { return (naughty & 0xFu) | ((uint32_t)(st & 63) << 4) | ((uint32_t)((st >> 8) & 1) << 10); }
+RR_HD uint32_t fz_bits_naughty(uint32_t pk) { return pk & 0xFu; }
+RR_HD int fz_bits_status(uint32_t pk) { return (int)((pk >> 4) & 63u) | (int)(((pk >> 10) & 1u) << 8); }
+RR_HD float bits_float(int32_t v) { float f; __builtin_memcpy(&f, &v, 4); return f; }
+RR_HD int32_t float_bits(float f) { int32_t v; __builtin_memcpy(&v, &f, 4); return v; }
+
 // actions: this arena's na discrete actions (thrust == nullptr) or 2*na thrust floats
 template <class C, typename O>
 RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64_t arena_gid, const int32_t *actions,
@@ -2069,11 +2085,15 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     R dist_sum0 = (R)0;
     for (int b = 0; b < C::NBP; b++) dist_sum0 = dist_sum0 + A.u.lidar[1][b];
     RR_SYNC();
+    constexpr bool FZP = C::NR <= 4 && C::NB <= 8; // what the packed word holds
+    uint64_t m_thr = 0; // robots whose thrust this step changes
     RR_FOR_LANES(l) {
+        bool thr_chg = false;
         if (l < C::NR) {
             // rectDblPriorStep = rectDbl.copy(): a fresh 20x40 rect centred at (10,20) moved by the centre setters (MyUtils.py:150-154)
             A.psx[l] = (R)10 + (A.p.rcx[l] - (R)10); A.psy[l] = (R)20 + (A.p.rcy[l] - (R)20);
             if (l < na) { // set_thrust (RR_Robot.py:100-102)
+                const int oL = A.i.thl[l], oR = A.i.thr[l];
                 if (thrust) {
                     A.i.thl[l] = (int)m_rint(thrust[2 * l]); A.i.thr[l] = (int)m_rint(thrust[2 * l + 1]);
                 } else {
@@ -2083,9 +2103,11 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
                         A.i.thr[l] = (a == 0 || a == 2 || a == 4) ? 1 : (a == 5 || a == 6) ? 0 : -1;
                     }
                 }
+                thr_chg = (A.i.thl[l] != oL) | (A.i.thr[l] != oR);
             }
         }
         if (l == 0) A.i.step += 1;
+        if (FZP) RR_VOTE(m_thr, l, thr_chg);
     }
     if (!thrust) for (int q = 0; q < na && q < C::NR; q++) { int a = actions[q]; if (a < 0 || a > 7) st |= ST_BAD_ACTION; }
     RR_SYNC();
@@ -2094,11 +2116,37 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     uint32_t prev_moved = 0, snap_moved = 0;
     int snap_at = -2; // sub-step whose end state the snapshot holds
     Hit fz = { 0, 0 }; // the frozen island (see substep)
+    uint32_t fz_bits = 0; // NaughtyBots members + status bits of one computed sub-step of the frozen island (fz_pack_bits)
+    if (FZP) { // the island the last step ended with, if its robots keep their thrust (see above)
+        const uint32_t fzp = o.snap() ? (uint32_t)A.i.fzp : 0u;
+        if (RR_UNLIKELY(fzp != 0u) && !((uint32_t)m_thr & fzp & 0xFu)) {
+            fz.r = fzp & 0xFu; fz.b = (fzp >> 4) & 0xFFu;
+            fz_bits = fzp >> 20;
+            const R ex = (R)bits_float(A.i.fexc);
+            RR_FOR_LANES(l) {
+                if (l < C::NR && ((fz.r >> l) & 1u)) A.wm[l] = (uint8_t)((fzp >> (12 + 2 * l)) & 3u);
+                if (l < C::NB && ((fz.b >> l) & 1u)) A.exc[l] = ex;
+            }
+            RR_SYNC();
+            RR_TRACE("E step begins frozen: robots %x balls %x\n", fz.r, fz.b);
+        }
+    }
+#if defined(RR_PROFILE_PHASES)
+    int dbg_work_ = 0;
+    const int dbg_frozen_ = (fz.r | fz.b) ? 1 : 0;
+#endif
 #pragma unroll 1
     for (int f = 0; f < RR_NUM_SUBSTEPS; f++) { // MOVES_PER_FRAME
         int work = 0;
         Hit hit = { 0, 0 };
-        substep(A, sp, naughty, st, prev_moved, work, fz, hit);
+        uint32_t n_sub = 0; // what THIS sub-step adds: a freeze keeps it for the frozen sub-steps of later steps
+        int st_sub = 0;
+        substep(A, sp, n_sub, st_sub, prev_moved, work, fz, hit);
+        naughty |= n_sub; st |= st_sub;
+#if defined(RR_PROFILE_PHASES) // diagnostic builds only: the step's contact work in status bits 20-29, "began frozen" in bit 30
+        dbg_work_ += work;
+#endif
+        if (FZP && RR_UNLIKELY(fz.r | fz.b)) { naughty |= fz_bits_naughty(fz_bits); st |= fz_bits_status(fz_bits); } // a frozen sub-step's share
         // An expensive sub-step: has the arena, or the island that made it expensive, stopped changing?  (The snapshot
         // costs a round trip to the arena's HBM record, so it is only taken when a whole-arena fixed point is possible --
         // no robot moved -- or when the sub-step exhausted the resolve loop.)
@@ -2109,8 +2157,11 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
             snapshot_compare_update(A, o.snap(), o.isnap(), have, chg_r, chg_re, chg_b, ax_diff);
             RR_TRACE("E snapshot at %d: have %d chg_r %x edges %x chg_b %x hit r %x b %x moved %x/%x work %d\n", f, (int)have, chg_r, chg_re, chg_b, hit.r, hit.b, prev_moved, snap_moved, work);
             if (have) {
+                const bool island_ok = (hit.r | hit.b) && !(chg_r & hit.r) && !(chg_b & hit.b) && !((prev_moved | snap_moved) & hit.r) &&
+                                       !robots_clamped(A, hit.r);
                 if (!(chg_r | chg_re | chg_b) && !ax_diff && snap_moved == prev_moved) {
                     RR_TRACE("E fixed point after sub-step %d\n", f);
+                    if (FZP && island_ok) { fz = hit; fz_bits = fz_pack_bits(n_sub, st_sub); } // for the NEXT step (this one is done)
                     break; // sub-steps f+1.. would reproduce this state bit for bit
                 }
                 // the island: everything that took part in a hit.  Unchanged since the previous sub-step, its robots'
@@ -2119,15 +2170,30 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
                 // its own move reads them.  So a frozen robot keeps making its move and being put back -- on its real edges --
                 // and the island is thawed the moment that move meets the walls differently (wm); a move that was clamped
                 // (its centre then depends on an edge value) is never frozen.
-                // (a one-robot arena is its own island: the whole-arena test above already covers it)
-                if (C::NR > 1 && (hit.r | hit.b) && !(chg_r & hit.r) && !(chg_b & hit.b) && !((prev_moved | snap_moved) & hit.r) &&
-                    !robots_clamped(A, hit.r)) {
+                // (a one-robot arena too: robot + ball squeezed against a wall is a whole-arena fixed point EXCEPT for those
+                // drifting edge bits, which is most of what a trained or chase policy runs into on preset T)
+                if (island_ok) {
                     RR_TRACE("E freeze robots %x balls %x after sub-step %d\n", hit.r, hit.b, f);
                     fz = hit;
+                    fz_bits = fz_pack_bits(n_sub, st_sub);
+                } else {
+                    RR_TRACE("E no freeze: island changed r %x b %x, moved %x, clamped %d\n", chg_r & hit.r, chg_b & hit.b, (prev_moved | snap_moved) & hit.r, (int)robots_clamped(A, hit.r));
                 }
             }
             snap_at = f; snap_moved = prev_moved;
         }
+    }
+    if (FZP) { // still frozen: the next step may start that way
+        int32_t fzw = 0, fex = 0;
+        if (RR_UNLIKELY(fz.r | fz.b)) {
+            R emax = (R)0;
+            uint32_t wmb = 0;
+            for (int b = 0; b < C::NB; b++) if ((fz.b >> b) & 1u) emax = py_max<R>(emax, A.exc[b]);
+            for (int r = 0; r < C::NR; r++) if ((fz.r >> r) & 1u) wmb |= (uint32_t)(A.wm[r] & 3) << (2 * r);
+            fzw = (int32_t)(fz.r | (fz.b << 4) | (wmb << 12) | (fz_bits << 20));
+            fex = float_bits((float)emax * 1.000001f + 1e-30f); // rounded up: a larger reach only thaws earlier
+        }
+        if (RR_IS_LANE0) { A.i.fzp = fzw; A.i.fexc = fex; }
     }
     substeps_end(A, prev_moved);
     RR_STAMP(9);
@@ -2181,6 +2247,9 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
         *o.reward() = (O)rew_h; *o.done() = done ? 1 : 0;
         if (o.reward_g()) *o.reward_g() = (O)rew_g;
         if (o.status()) *o.status() = st | (int)(naughty << 16); // bits 16..: robots NaughtyBots flagged this step
+#if defined(RR_PROFILE_PHASES)
+        if (o.status()) *o.status() |= ((dbg_work_ > 1023 ? 1023 : dbg_work_) << 20) | (dbg_frozen_ << 30);
+#endif
         // episode bookkeeping for logging (the caller sums `score` the same way, Training_DQN_pytorch.py:345-346)
         A.i.ep_len += 1;
         if (!sp.acc_external) { A.p.acc[0] += rew_h; A.p.acc[1] += rew_g; }

@@ -57,6 +57,7 @@ template <class C> static void set_state(Emu<C> *e, const double *robots, const 
     }
     A.i.step = step;
     A.i.fault = 0;
+    A.i.fzp = 0;
     derive(A, e->sp);
 }
 template <class C> static void get_state(Emu<C> *e, double *robots, int32_t *ri, double *balls, int32_t *step) {
@@ -140,7 +141,7 @@ void emu_set_poses(Handle *h, const double *rxyr, const double *bxyv) {
                                                                    (typename CC::Real)rxyr[3 * r + 1], (typename CC::Real)rxyr[3 * r + 2]);
              for (int b = 0; b < CC::NB; b++) ball_set_clean_lane(e->A, b, (typename CC::Real)bxyv[4 * b], (typename CC::Real)bxyv[4 * b + 1],
                                                                   (typename CC::Real)bxyv[4 * b + 2], (typename CC::Real)bxyv[4 * b + 3]);
-             e->A.i.step = 0; derive(e->A, e->sp));
+             e->A.i.step = 0; e->A.i.fzp = 0; derive(e->A, e->sp));
 }
 // same bracketing as rr_step: snapshot -> step kernel phases -> keeper program (only for a non-default program)
 extern "C++" {

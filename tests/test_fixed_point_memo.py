@@ -146,3 +146,50 @@ def test_island_thaw_paths_are_exact_G():
         for k in fired:
             fired[k] += c[k]
     assert fired["freeze"] > 100 and fired["thaw in phase 1"] > 50 and fired["thaw in phase 2"] > 10, fired
+
+
+def _rollout_seq(preset, state, acts, memo, poke=None):
+    """like _rollout, with one action per step; poke = (step index, fn(env)) mutates the env from outside before that step."""
+    el.lib().emu_debug_memo(int(memo))
+    try:
+        env = el.EmuEnv(preset, time_limit=1, auto_reset=1)
+        env.set_state(*state)
+        out = []
+        for k, a in enumerate(acts):
+            if poke is not None and poke[0] == k:
+                poke[1](env)
+            r = env.step(a)
+            st = env.get_state()
+            out.append((r["obs"].tobytes(), r["obs_g"].tobytes(), r["reward"], r["reward_g"], r["done"], r["status"], r["naughty"],
+                        st["robots"].tobytes(), st["robots_i"].tobytes(), st["balls"].tobytes(), st["step"]))
+        return out
+    finally:
+        el.lib().emu_debug_memo(1)
+
+
+@pytest.mark.parametrize("preset", ["T", "G"])
+def test_freeze_carried_across_steps_is_exact_on_stuck_arenas_of_a_chase_rollout(preset):
+    """Arenas of the slowest wavefronts of a chase-policy rollout on the MI355X (tools/chase_monsters.py, stuck_fixtures.py):
+    a robot driving a ball into a wall (T: a one-robot arena whose robot edges keep drifting in the last bits -- frozen as an
+    island, not as a whole-arena fixed point), ball clusters in front of a robot (G).  Eight steps each: the robot keeps its
+    action most of the time (the island the step ended with is carried into the next one), changes it now and then (the island
+    is recomputed), and once the state is rewritten from outside (nothing may be carried over).  Shortcuts on == off, bit for bit."""
+    d = np.load(os.path.join(HERE, "data", f"stuck_chase_{preset}.npz"))
+    n = len(d["step"]) if preset == "T" else 24
+    fired = {"step begins frozen": 0, "freeze": 0, "thaw": 0}
+    for a in range(n):
+        rng = np.random.RandomState(100 + a)
+        state = (d["robots"][a], d["robots_i"][a], d["balls"][a], int(d["step"][a]))
+        acts = [d["actions"][a] if rng.rand() < 0.75 else rng.randint(0, 8, d["actions"][a].shape).astype(np.int32) for _ in range(8)]
+
+        def rewrite(env):  # rr_set_state with the state it has: the same physics, but nothing frozen may survive it
+            s = env.get_state()
+            env.set_state(s["robots"], s["robots_i"], s["balls"], s["step"])
+        poke = (5, rewrite) if a % 3 == 0 else None
+        on = _rollout_seq(preset, state, acts, True, poke)
+        off = _rollout_seq(preset, state, acts, False, poke)
+        assert on == off, (preset, a)
+        c = _count_events(lambda: _rollout_seq(preset, state, acts, True, poke), tuple(fired))
+        for k in fired:
+            fired[k] += c[k]
+    assert fired["step begins frozen"] >= (150 if preset == "T" else 5) and fired["freeze"] >= (40 if preset == "T" else 5), fired
