@@ -172,3 +172,68 @@ def test_step_can_be_captured_into_a_hip_graph():
         o, r, d, info = eager.step(acts[s])
         torch.cuda.synchronize()
         assert torch.equal(out[0], o) and torch.equal(out[1], r) and torch.equal(out[2].bool(), d) and torch.equal(out[5], info.status), s
+
+
+@pytest.mark.parametrize("preset", ["T", "G"])
+def test_islands_carried_across_steps_shortcuts_off_equals_on(preset):
+    """Stuck arenas from the slowest wavefronts of a chase-policy rollout (tests/data/stuck_chase_*.npz): ten steps in which
+    every robot keeps its action most of the time (the frozen island is carried into the next step), changes it now and then
+    (recomputed), with one rr_set_state of the state they have in between (nothing may be carried) -- shortcuts on == off."""
+    d = np.load(os.path.join(HERE, "data", f"stuck_chase_{preset}.npz"))
+    n = len(d["step"])
+    rng = np.random.RandomState(5)
+    acts = []
+    for s in range(10):
+        a = d["actions"].copy()
+        ch = rng.rand(n) < 0.25
+        a[ch] = rng.randint(0, 8, a[ch].shape)
+        acts.append(torch.as_tensor(a.astype(np.int32), device="cuda"))
+    outs = []
+    for sw in ({}, {"RR_NO_MEMO": 1, "RR_NO_ORDER": 1}):
+        env = _env(n, preset, **sw)
+        env.set_state(d["robots"], d["robots_i"], d["balls"], d["step"].astype(np.int32))
+        res = []
+        for s in range(10):
+            if s == 6:  # rewrite the arenas with the state they have
+                st = env.get_state()
+                env.set_state(st["robots"], st["robots_i"], st["balls"], st["step"])
+            o, r, dn, info = env.step_f64(acts[s])
+            st = env.get_state()
+            res.append([t.cpu().numpy().copy() for t in (o, r, dn, info.status, st["robots"], st["robots_i"], st["balls"])])
+        outs.append(res)
+    assert _same(outs[0], outs[1])
+
+
+def test_full_size_chase_rollout_independent_of_shortcuts():
+    """65,536 T arenas, 120 steps of the chase policy (robots end up driving their ball into a wall: islands freeze, are
+    carried across steps, thaw on the 10 % random actions, episodes end and arenas are re-placed inside the rollout)."""
+    import roborugby_amd as rr
+    n = 65536
+    finals = []
+    for sw in ({}, {"RR_NO_MEMO": 1, "RR_NO_ORDER": 1}):
+        old = {k: os.environ.get(k) for k in sw}
+        os.environ.update({k: str(v) for k, v in sw.items()})
+        try:
+            env = rr.BatchedRoboRugbyEnv(n, preset="T", seed=0)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        gen = torch.Generator(device="cuda"); gen.manual_seed(17)
+        obs = env.reset()
+        st = env.get_state()
+        st["step"][: n // 4] = env.preset.game_len_steps - 60  # a quarter of the arenas is re-placed half-way
+        env.set_state(st["robots"], st["robots_i"], st["balls"], st["step"])
+        rew = torch.zeros(n, device="cuda", dtype=torch.float64)
+        nd = 0
+        for s in range(120):
+            dlt = (obs[:, 1] - obs[:, 0] + 540.0) % 360.0 - 180.0
+            a = torch.where(dlt.abs() < 8, 0, torch.where(dlt > 0, 2, 3)).to(torch.int32)
+            noise = torch.rand(n, generator=gen, device="cuda") < 0.1
+            a = torch.where(noise, torch.randint(0, 8, (n,), generator=gen, device="cuda", dtype=torch.int32), a).view(n, 1)
+            obs, r, d, info = env.step(a)
+            rew += r.double(); nd += int(d.sum())
+        st = env.get_state()
+        finals.append((obs.cpu().numpy(), rew.cpu().numpy(), st["robots"].cpu().numpy(), st["balls"].cpu().numpy(), st["robots_i"].cpu().numpy(), nd))
+    assert finals[0][-1] >= n // 4
+    for x, y in zip(finals[0][:-1], finals[1][:-1]):
+        assert np.array_equal(x, y, equal_nan=True)
