@@ -753,6 +753,7 @@ template <class C> RR_HD uint32_t detect_robot_pairs(Arena<C> &A) {
 template <class C, bool CACHED> RR_HD uint32_t detect_ball_robot(Arena<C> &A, const SimParams<typename C::Real> &sp) {
     using R = typename C::Real;
     // broad phase: one lane per ball sweeps the robots (radius bound, then the robot-frame bound) and publishes its mask
+    RR_T0();
     uint64_t anyc = 0;
     RR_FOR_LANES(l) {
         bool c = false;
@@ -765,6 +766,7 @@ template <class C, bool CACHED> RR_HD uint32_t detect_ball_robot(Arena<C> &A, co
         RR_VOTE(anyc, l, c);
     }
     if (!RR_UNLIKELY(anyc)) return 0;
+    if (CACHED) RR_STAMP(26);
     RR_SYNC();
     uint32_t close = 0;
     for (int b = 0; b < C::NB; b++) close |= (uint32_t)A.brc[b] << (b * C::NR);
@@ -775,6 +777,7 @@ template <class C, bool CACHED> RR_HD uint32_t detect_ball_robot(Arena<C> &A, co
         RR_SYNC();
         ensure_sides(A);
     }
+    if (CACHED) RR_STAMP(27);
     uint32_t pairs = 0;
     constexpr int NT = C::NB * C::NR * 2; // task = (pair, diameter)
     for (int base = 0; base < NT; base += C::VW) {
@@ -814,6 +817,7 @@ template <class C, bool CACHED> RR_HD uint32_t detect_ball_robot(Arena<C> &A, co
         for (int q = 0; q < C::VW / 2; q++)
             if ((m >> (2 * q)) & 3ull) pairs |= 1u << ((base >> 1) + q);
     }
+    if (CACHED) RR_STAMP(28);
     if (pairs && !CACHED) { // rare: the responses read the cached inner-square offsets and side slopes
         RR_FOR_LANES(l) {
             if (l < C::NR) refresh_inner_lane(A, sp, l);
@@ -1047,10 +1051,13 @@ template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, const SimParams<
     force_diameters(A, r, bc, dia);
     R mvx = 0, mvy = 0;
     bool done = false;
+    RR_T0();
     const int k = first_surface_hit(A, r, dia, (R)0);
     const int c = (k >= 0) ? -1 : first_corner_hit(A, r, bc, (R)7);
+    RR_STAMP(23);
     if (k >= 0 || c >= 0) {
         const PrevPose<R> pv = robot_prev_frame(A, sp, r, bots_moved);
+        RR_STAMP(24);
         if (k >= 0) {
             const int sd = k >> 1, d = k & 1;
             RR_TRACE("E bounce surface s=%d d=%d b=%d r=%d v=(%.17g,%.17g)\n", sd, d, b, r, (double)vx, (double)vy);
@@ -1095,6 +1102,7 @@ template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, const SimParams<
         ball_exc_update(A, b);
     }
     RR_SYNC();
+    RR_STAMP(25);
 }
 // bounce_balls (RR_TrashyPhysics.py:248-316)
 template <class C> RR_HDN void bounce_balls(Arena<C> &A, int i, int j, int &st) {

@@ -1,7 +1,7 @@
 """Diagnostic (-DRR_PROFILE_PHASES build, RR_NO_ORDER=1): roll a G (or T) batch under the chase policy and, for every step after
 the warm-up, keep the pre-step state + actions of the arenas of the SLOWEST wavefront together with the distribution of the
 wavefront run times -- what bounds a contact-rich launch.  Output: gpurun_out/chase_monsters_<preset>.npz
-usage: RR_NO_ORDER=1 RR_LIB_PATH=<diag .so> python tools/chase_monsters.py [G|T] [steps] [warmup]"""
+usage: RR_NO_ORDER=1 RR_LIB_PATH=<diag .so> python tools/chase_monsters.py [G|T] [steps] [warmup] [chase|random]"""
 import ctypes as C, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,6 +10,7 @@ from roborugby_amd import _lib
 preset = sys.argv[1] if len(sys.argv) > 1 else "G"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 warm = int(sys.argv[3]) if len(sys.argv) > 3 else 150
+policy = sys.argv[4] if len(sys.argv) > 4 else "chase"
 n = 65536
 env = rr.BatchedRoboRugbyEnv(n, preset=preset, seed=0)
 obs = env.reset()
@@ -20,6 +21,8 @@ waves = n // apw
 buf = (C.c_ulonglong * (2 * waves))()
 g = torch.Generator(device='cuda'); g.manual_seed(1)
 def act(o):
+    if policy == "random":
+        return torch.randint(0, 8, (n, na), generator=g, device='cuda', dtype=torch.int32)
     d = (o[:, 1] - o[:, 0] + 540.0) % 360.0 - 180.0
     a0 = torch.where(d.abs() < 8, 0, torch.where(d > 0, 2, 3)).to(torch.int32)
     r = torch.randint(0, 8, a0.shape, generator=g, device='cuda', dtype=torch.int32)
@@ -53,12 +56,12 @@ for s in range(warm + steps):
                         slow_robots_i=before['robots_i'][ars].cpu().numpy(), slow_balls=before['balls'][ars].cpu().numpy(),
                         slow_stepc=before['step'][ars].cpu().numpy(), all_us=d)
 pct = np.array(pct)
-print(f"{preset} chase: wavefront run time us  p50 {pct[:,0].mean():.0f}  p90 {pct[:,1].mean():.0f}  p99 {pct[:,2].mean():.0f}  p99.9 {pct[:,3].mean():.0f}  "
+print(f"{preset} {policy}: wavefront run time us  p50 {pct[:,0].mean():.0f}  p90 {pct[:,1].mean():.0f}  p99 {pct[:,2].mean():.0f}  p99.9 {pct[:,3].mean():.0f}  "
       f"max {pct[:,4].mean():.0f}   launch span {pct[:,5].mean():.0f}  event time {pct[:,6].mean():.0f}  "
       f"sum of wave times / 2048 slots {pct[:,7].mean():.0f}")
 print("slowest wave per step (step, wave, us):", [(f['step'], f['wave'], int(f['us'])) for f in found])
 for f in found[::4]:
     print("  step", f['step'], "wave", f['wave'], int(f['us']), "us: work", f['work'].tolist(), "began frozen", f['frozen'].tolist())
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-np.savez(os.path.join(ROOT, 'gpurun_out', f'chase_monsters_{preset}.npz'), pct=pct, **slow_rec,
+np.savez(os.path.join(ROOT, 'gpurun_out', f'chase_monsters_{preset}.npz' if policy == 'chase' else f'{policy}_monsters_{preset}.npz'), pct=pct, **slow_rec,
          **{f"{k}_{i}": v for i, f in enumerate(found) for k, v in f.items()})

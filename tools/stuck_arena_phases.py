@@ -29,8 +29,10 @@ print(f"{preset} stuck arena #{idx}: step latency median {ts[len(ts)//2]:.0f} us
 names = ["(unused)", "hooks + moves + broad", "resolve_bot (if close)", "push (if close)", "roll + broad", "resolve loop (if close)", "undo (if failed)", "(unused)",
          "step_begin", "(12 substeps total)", "rewards", "obs+out", "load+derive", "store",
          "  resolve: ball-ball detect + bounces", "  resolve: ball-robot detect", "  resolve: bounce_ball_off_bot", "  resolve: wall detect + bounce",
-         "  undo: detections", "  undo: undo lanes", "  push: apply_force_to_ball", "  push: bounce_ball_off_bot", "  push: ball-robot detect (no cache)"]
-v = list(buf)[:23]
+         "  undo: detections", "  undo: undo lanes", "  push: apply_force_to_ball", "  push: bounce_ball_off_bot", "  push: ball-robot detect (no cache)",
+         "    bounce_ball_off_bot: surface / corner search", "    bounce_ball_off_bot: prior-frame pose", "    bounce_ball_off_bot: response + write",
+         "    detect (cached): broad phase + ballot", "    detect (cached): mask gather + cache checks", "    detect (cached): narrow-phase round(s)"]
+v = list(buf)[:29]
 tot = sum(v[i] for i in (8, 9, 10, 11, 12, 13))
 for i, nm in enumerate(names):
     if v[i]: print(f"  {nm:40s} {v[i] / K:10.0f} ticks/step {100.0 * v[i] / tot:5.1f}%")
