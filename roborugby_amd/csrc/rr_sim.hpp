@@ -779,6 +779,50 @@ template <class C, bool CACHED> RR_HD uint32_t detect_ball_robot(Arena<C> &A, co
     }
     if (CACHED) RR_STAMP(27);
     uint32_t pairs = 0;
+    if constexpr (C::VW >= 8) {
+        // Narrow phase, one lane per (close pair, diameter, side): eight lanes per pair, the close pairs taken in mask order,
+        // VW / 8 of them per round.  A lane intersects ITS diameter with ITS side (and, for the first diameter, tests the side's
+        // corner number against the radius): two dependent divisions instead of the five of a lane that sweeps the four sides,
+        // and no round is spent on a ball's pairs that are not close.  The pair's hit is the OR over its eight lanes -- the very
+        // predicates of RR_TrashyPhysics.py:39-69 on the very operands, only spread differently.
+        constexpr int PPR = C::VW / 8;
+#pragma unroll 1
+        for (uint32_t todo = close; todo;) {
+            int prs[PPR];
+            for (int q = 0; q < PPR; q++) { prs[q] = todo ? low_bit(todo) : -1; todo &= todo - 1; }
+            uint64_t m = 0;
+            RR_FOR_LANES(l) {
+                bool hit = false;
+                int pr = prs[0];
+                for (int q = 1; q < PPR; q++) pr = ((l >> 3) == q) ? prs[q] : pr; // by value: no dynamically indexed local array
+                if (pr >= 0) {
+                    const int d = (l >> 2) & 1, sd = l & 3, r = pr % C::NR, b = pr / C::NR;
+                    int st = 0;
+                    V2<R> bc = { A.p.bcx[b], A.p.bcy[b] };
+                    if (d == 0) hit = dist<R>(robot_corner(A, r, sd), bc) < (R)7;
+                    R ox, oy;
+                    if (CACHED) {
+                        ox = A.u.irel[r][2 * d]; oy = A.u.irel[r][2 * d + 1];
+                    } else {
+                        R iq[8];
+                        corners_for<R>(norm360<R>(A.p.rrot[r] + (R)45), sp.inner_h, sp.inner_h, sp.inner_cdist, iq);
+                        ox = d == 0 ? iq[0] : iq[2]; oy = d == 0 ? iq[1] : iq[3];
+                    }
+                    Seg<R> dia = { { bc.x + ox, bc.y + oy }, { bc.x + -ox, bc.y + -oy } };
+                    R md, cd, ms, cs;
+                    slope_yint<R>(dia.a, dia.b, md, cd, st);
+                    Seg<R> side = robot_side(A, r, sd);
+                    if (CACHED) { ms = A.sm[r][sd]; cs = A.sc[r][sd]; }
+                    else slope_yint<R>(side.a, side.b, ms, cs, st);
+                    V2<R> q = intersect_mb<R>(ms, cs, side.a.x, md, cd, dia.a.x);
+                    hit = hit | (within<R>(q, side, (R)0) & within<R>(q, dia, (R)0));
+                }
+                RR_VOTE(m, l, hit);
+            }
+            for (int q = 0; q < PPR; q++)
+                if (prs[q] >= 0 && ((m >> (8 * q)) & 0xFFull)) pairs |= 1u << prs[q];
+        }
+    } else {
     constexpr int NT = C::NB * C::NR * 2; // task = (pair, diameter)
     for (int base = 0; base < NT; base += C::VW) {
         constexpr uint32_t ALL = (C::VW >= 64) ? 0xFFFFFFFFu : ((1u << (C::VW / 2)) - 1u);
@@ -816,6 +860,7 @@ template <class C, bool CACHED> RR_HD uint32_t detect_ball_robot(Arena<C> &A, co
         }
         for (int q = 0; q < C::VW / 2; q++)
             if ((m >> (2 * q)) & 3ull) pairs |= 1u << ((base >> 1) + q);
+    }
     }
     if (CACHED) RR_STAMP(28);
     if (pairs && !CACHED) { // rare: the responses read the cached inner-square offsets and side slopes
