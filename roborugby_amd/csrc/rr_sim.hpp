@@ -1239,14 +1239,16 @@ template <class C> RR_HD void ball_undo_lane(Arena<C> &A, int b) {
 }
 
 // ------------------------------------------------------------------------------------------------ sub-step pieces (RR_EnvBase.py:303-454)
-template <class C> RR_HDN void resolve_bot_collisions(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &bots_moved, uint32_t &naughty, int &st, int &work, Hit &hit) {
-    if (C::NPR == 0) return;
+// returns whether any pair collided (i.e. whether any robot may have been put back)
+template <class C> RR_HDN bool resolve_bot_collisions(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &bots_moved, uint32_t &naughty, int &st, int &work, Hit &hit) {
+    if (C::NPR == 0) return false;
     uint32_t pairs = detect_robot_pairs(A);
+    if (!pairs) return false;
     int attempts = 0;
     while (pairs) {
         attempts++;
         work += 4;
-        if (attempts > C::NR) { st |= ST_BOT_RESOLVE_FAIL; return; }
+        if (attempts > C::NR) { st |= ST_BOT_RESOLVE_FAIL; return true; }
 #pragma unroll 1
         for (uint32_t todo = pairs; todo; todo &= todo - 1) {
             const int p = low_bit(todo);
@@ -1257,7 +1259,7 @@ template <class C> RR_HDN void resolve_bot_collisions(Arena<C> &A, const SimPara
             if (A.i.thl[i] != 0 || A.i.thr[i] != 0) naughty |= 1u << i;
             if (A.i.thl[j] != 0 || A.i.thr[j] != 0) naughty |= 1u << j;
             uint32_t undo = bots_moved & ((1u << i) | (1u << j));
-            if (!undo) { st |= ST_BOT_STUCK; return; }
+            if (!undo) { st |= ST_BOT_STUCK; return true; }
             bots_moved &= ~undo;
             RR_FOR_LANES(l) {
                 if (l < C::NR && (undo & (1u << l))) robot_undo_lane(A, sp, l);
@@ -1266,6 +1268,7 @@ template <class C> RR_HDN void resolve_bot_collisions(Arena<C> &A, const SimPara
         }
         pairs = detect_robot_pairs(A);
     }
+    return true;
 }
 template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t bots_moved, int &st, int &work, Hit &hit) {
     bool naughty = true;
@@ -1580,8 +1583,10 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
         m_rr = 1; m_br = 1;
     }
     if (RR_UNLIKELY(m_rr)) {
-        resolve_bot_collisions(A, sp, bots_moved, naughty, st, work, hit);
-        m_br = 1; // an undone robot changes the ball-robot picture: let the full detection decide
+        // an undone robot changes the ball-robot picture: let the full detection decide.  (No pair really touching -- most
+        // of the time two robots merely pass within 51.5 px of each other -- leaves every robot where phase 1 put it, and
+        // phase 1's own ball-robot bound stands.)
+        if (resolve_bot_collisions(A, sp, bots_moved, naughty, st, work, hit)) m_br = 1;
     }
     RR_STAMP(2);
     if (RR_UNLIKELY(m_br)) { // _push_balls (RR_EnvBase.py:335-339): frozen hit list, ball-major order
