@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--log-interval", type=int, default=25, help="steps between RCCL all-gathers of episode returns")
     ap.add_argument("--fuse", type=int, default=1, help="steps per launch (rr_rollout, open-loop extension; 1 = one launch per "
                     "step like the reference's gym API -- the headline)")
+    ap.add_argument("--pipeline", type=int, default=1, help="extension, not the headline: the arenas as P independent shard envs "
+                    "(arena_offset) stepped on P HIP streams, so that consecutive launches of different shards overlap and the chip "
+                    "does not drain at the end of every step; random policy, one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -93,8 +96,73 @@ def chase_actions(obs, noise, gen):
     return torch.where(m, r, a)
 
 
+def pipelined(args):
+    """--pipeline P: the same 65,536 arenas, the same K steps each, as P shard envs on P streams.  A shard's step s+1 only waits
+    for its own step s, so while one shard's launch drains (a launch ends with its slowest wavefront) the other's fills the chip.
+    Results per arena are the single batch's bit for bit (arena_offset keys the reset RNG; tests/test_gpu_dist.py).  A caller
+    with a policy in the loop has to feed the shards separately (two actor groups) to get this overlap."""
+    import torch
+    import roborugby_amd as rr
+    assert args.gpus == 1 and args.policy == "random" and args.fuse == 1 and args.arenas % args.pipeline == 0
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    P, N, K, W = args.pipeline, args.arenas, args.steps, args.warmup
+    n = N // P
+    envs = [rr.BatchedRoboRugbyEnv(n, preset=args.preset, device=dev, seed=0, time_limit=True, auto_reset=True, dtype=args.dtype,
+                                   arena_offset=i * n) for i in range(P)]
+    p = envs[0].preset
+    na = p.nr
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    acts = torch.randint(0, 8, (K + W, N, na), generator=gen, device=dev, dtype=torch.int32)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(P)]
+    outs = [(torch.empty(n, 11, device=dev), torch.empty(n, device=dev), torch.empty(n, dtype=torch.uint8, device=dev),
+             torch.empty(n, 11, device=dev) if p.nr_grumpy else None, torch.empty(n, device=dev),
+             torch.empty(n, dtype=torch.int32, device=dev)) for _ in range(P)]
+    for e in envs:
+        e.reset()
+    torch.cuda.synchronize()
+
+    def run(k0, k1):
+        for s in range(k0, k1):
+            for i, e in enumerate(envs):
+                with torch.cuda.stream(streams[i]):
+                    e.step(acts[s, i * n:(i + 1) * n], out=outs[i])
+
+    run(0, W)
+    torch.cuda.synchronize()
+    cnt0 = sum(int(e.episode_stats()[3].sum().item()) for e in envs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(W, W + K)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    cnt1 = sum(int(e.episode_stats()[3].sum().item()) for e in envs)
+    resets = cnt1 - cnt0 - sum(int(o[2].sum().item()) for o in outs)
+    steps = N * K - max(resets, 0)
+    bytes_per_step = p.algorithmic_bytes_per_step(na)
+    achieved = bytes_per_step * steps / dt / 1e9
+    line = {"metric": "env_steps_per_sec", "value": steps / dt, "unit": "env-steps/s", "n_gpus": 1, "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"{N} parallel arenas per GPU as {P} independent shards of {n} on {P} HIP streams (launches of "
+                                   f"different shards overlap), SimpleDuel3 preset {args.preset}, random-policy rollout, {na} action(s)/arena, "
+                                   f"auto-reset on done, {envs[0].lanes_per_env()} lanes per arena",
+                       "arenas_per_gpu": N, "preset": args.preset, "policy": "random", "lanes_per_arena": envs[0].lanes_per_env(),
+                       "sharding": "single GPU", "steps_per_launch": 1, "pipeline": P},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_step", "kernel_ms": None,
+                         "algorithmic_bytes_per_env_step": bytes_per_step, "record_bytes_per_env": envs[0].state_bytes_per_env(),
+                         "note": "overlapping launches: achieved = algorithmic bytes of all arenas per step / wall time per step"}}
+    print(json.dumps(line), flush=True)
+    for e in envs:
+        e.close()
+
+
 def main():
     args = parse()
+    if args.pipeline > 1:
+        return pipelined(args)
     maybe_relaunch(args)
     import torch
     import roborugby_amd as rr

@@ -237,3 +237,34 @@ def test_full_size_chase_rollout_independent_of_shortcuts():
     assert finals[0][-1] >= n // 4
     for x, y in zip(finals[0][:-1], finals[1][:-1]):
         assert np.array_equal(x, y, equal_nan=True)
+
+
+def test_shard_envs_on_two_streams_equal_one_batch():
+    """bench.py --pipeline 2: the batch as two shard envs (arena_offset) stepped on two HIP streams with overlapping launches --
+    every arena's trajectory is the single batch's, bit for bit."""
+    import roborugby_amd as rr
+    n, S = 16384, 30
+    gen = torch.Generator(device="cuda"); gen.manual_seed(2)
+    acts = torch.randint(0, 8, (S, n, 4), generator=gen, device="cuda", dtype=torch.int32)
+    whole = rr.BatchedRoboRugbyEnv(n, preset="G", seed=5)
+    whole.reset()
+    for s in range(S):
+        ow, rw, dw, _ = whole.step(acts[s])
+    halves = [rr.BatchedRoboRugbyEnv(n // 2, preset="G", seed=5, arena_offset=i * (n // 2)) for i in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    torch.cuda.synchronize()
+    res = [None, None]
+    for i, e in enumerate(halves):
+        with torch.cuda.stream(streams[i]):
+            e.reset()
+    for s in range(S):
+        for i, e in enumerate(halves):
+            with torch.cuda.stream(streams[i]):
+                res[i] = e.step(acts[s, i * (n // 2):(i + 1) * (n // 2)])
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([res[0][0], res[1][0]]), ow) and torch.equal(torch.cat([res[0][1], res[1][1]]), rw)
+    a = whole.get_state()
+    b = [h.get_state() for h in halves]
+    for k in ("robots", "balls", "robots_i"):
+        x, y = a[k], torch.cat([b[0][k], b[1][k]])
+        assert torch.equal(x.nan_to_num(7e77), y.nan_to_num(7e77)) if x.dtype.is_floating_point else torch.equal(x, y)
