@@ -1017,6 +1017,40 @@ RR_HD int first_surface_hit(Arena<C> &A, int r, const Seg<typename C::Real> dia[
     }
     return hits ? low_bit(hits) : -1;
 }
+// The push runs apply_force_to_ball and bounce_ball_off_bot back to back on the same pair, and the first only writes the ball's
+// force and mass: both searches look at the same eight intersections and differ in the diameter's buffer alone.  One sweep, two
+// ballots: ka = first candidate under bufa, kb under bufb.
+template <class C>
+RR_HD void first_surface_hit2(Arena<C> &A, int r, const Seg<typename C::Real> dia[2], typename C::Real bufa, typename C::Real bufb,
+                              int &ka, int &kb) {
+    using R = typename C::Real;
+    ensure_sides(A);
+    uint32_t ha = 0, hb = 0;
+    for (int base = 0; base < 8; base += C::VW) {
+        uint64_t ma = 0, mb = 0;
+        RR_FOR_LANES(l) {
+            bool hita = false, hitb = false;
+            const int t = base + l;
+            if (t < 8) {
+                const int sd = t >> 1, d = t & 1;
+                int st = 0;
+                Seg<R> side = robot_side(A, r, sd);
+                const Seg<R> di = pick_dia<R>(dia, d);
+                R md, cd;
+                slope_yint<R>(di.a, di.b, md, cd, st);
+                V2<R> I = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, md, cd, di.a.x);
+                const bool ws = within<R>(I, side, (R)0);
+                hita = ws & within<R>(I, di, bufa);
+                hitb = ws & within<R>(I, di, bufb);
+            }
+            RR_VOTE(ma, l, hita);
+            RR_VOTE(mb, l, hitb);
+        }
+        ha |= (uint32_t)(ma << base); hb |= (uint32_t)(mb << base);
+    }
+    ka = ha ? low_bit(ha) : -1;
+    kb = hb ? low_bit(hb) : -1;
+}
 // same idea for the corner-contact search: first corner (TL,TR,BL,BR) closer to the ball centre than `rad`
 template <class C>
 RR_HD int first_corner_hit(Arena<C> &A, int r, V2<typename C::Real> bc, typename C::Real rad) {
@@ -1034,7 +1068,8 @@ RR_HD int first_corner_hit(Arena<C> &A, int r, V2<typename C::Real> bc, typename
     return hits ? low_bit(hits) : -1;
 }
 // apply_force_to_ball (RR_TrashyPhysics.py:88-152)
-template <class C> RR_HDN void apply_force_to_ball(Arena<C> &A, const SimParams<typename C::Real> &sp, int r, int b, uint32_t bots_moved, int &st) {
+// (kpre: the surface search's result when the caller already has it, -2 = search here)
+template <class C> RR_HDN void apply_force_to_ball(Arena<C> &A, const SimParams<typename C::Real> &sp, int r, int b, uint32_t bots_moved, int &st, int kpre = -2) {
     using R = typename C::Real;
     const R cbuf = (R).5;
     V2<R> bc = { A.p.bcx[b], A.p.bcy[b] }, rc = { A.p.rcx[r], A.p.rcy[r] };
@@ -1042,7 +1077,7 @@ template <class C> RR_HDN void apply_force_to_ball(Arena<C> &A, const SimParams<
     force_diameters(A, r, bc, dia);
     R fx = A.bfx[b], fy = A.bfy[b];
     bool done = false;
-    const int k = first_surface_hit(A, r, dia, cbuf);
+    const int k = kpre != -2 ? kpre : first_surface_hit(A, r, dia, cbuf);
     if (k >= 0) {
         const int sd = k >> 1, d = k & 1;
         RR_TRACE("E force surface s=%d d=%d b=%d r=%d\n", sd, d, b, r);
@@ -1086,7 +1121,7 @@ template <typename R> RR_HD void bounce_reflect(V2<R> con, R &vx, R &vy, R &d2) 
     if ((pry < (R)0 && con.y > (R)0) || (pry > (R)0 && con.y < (R)0)) vy = -pry * (R).8 * (R).8;
 }
 // bounce_ball_off_bot (RR_TrashyPhysics.py:155-245)
-template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, const SimParams<typename C::Real> &sp, int r, int b, uint32_t bots_moved, int &st) {
+template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, const SimParams<typename C::Real> &sp, int r, int b, uint32_t bots_moved, int &st, int kpre = -2) {
     using R = typename C::Real;
     R vx = A.p.bvx[b], vy = A.p.bvy[b];
     if (vx == (R)0 && vy == (R)0) return;
@@ -1097,7 +1132,7 @@ template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, const SimParams<
     R mvx = 0, mvy = 0;
     bool done = false;
     RR_T0();
-    const int k = first_surface_hit(A, r, dia, (R)0);
+    const int k = kpre != -2 ? kpre : first_surface_hit(A, r, dia, (R)0);
     const int c = (k >= 0) ? -1 : first_corner_hit(A, r, bc, (R)7);
     RR_STAMP(23);
     if (k >= 0 || c >= 0) {
@@ -1513,9 +1548,18 @@ RR_HD void push_balls(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32
     for (uint32_t todo = br; todo; todo &= todo - 1) {
         const int p = low_bit(todo);
         hit.b |= 1u << (p / C::NR); hit.r |= 1u << (p % C::NR);
-        apply_force_to_ball(A, sp, p % C::NR, p / C::NR, bots_moved, st);
+        int kf, kb;
+        {
+            using R = typename C::Real;
+            const int r = p % C::NR, b = p / C::NR;
+            V2<R> bc = { A.p.bcx[b], A.p.bcy[b] };
+            Seg<R> dia[2];
+            force_diameters(A, r, bc, dia);
+            first_surface_hit2(A, r, dia, (R).5, (R)0, kf, kb);
+        }
+        apply_force_to_ball(A, sp, p % C::NR, p / C::NR, bots_moved, st, kf);
         RR_STAMP(20);
-        bounce_ball_off_bot(A, sp, p % C::NR, p / C::NR, bots_moved, st);
+        bounce_ball_off_bot(A, sp, p % C::NR, p / C::NR, bots_moved, st, kb);
         RR_STAMP(21);
     }
     if (br) { // the pushed balls' force and velocity changed: their roll bound with them
