@@ -97,66 +97,67 @@ def chase_actions(obs, noise, gen):
 
 
 def pipelined(args):
-    """--pipeline P: the same 65,536 arenas, the same K steps each, as P shard envs on P streams.  A shard's step s+1 only waits
-    for its own step s, so while one shard's launch drains (a launch ends with its slowest wavefront) the other's fills the chip.
-    Results per arena are the single batch's bit for bit (arena_offset keys the reset RNG; tests/test_gpu_dist.py).  A caller
-    with a policy in the loop has to feed the shards separately (two actor groups) to get this overlap."""
+    """--pipeline P: the same 65,536 arenas, the same K steps each, as P shard envs on P streams (roborugby_amd.ShardedPipeline).
+    A shard's step s+1 only waits for its own step s (and its own policy call), so while one shard's launch drains -- a launch
+    ends with its slowest wavefront -- another's fills the chip.  Results per arena are the single batch's bit for bit
+    (arena_offset keys the reset RNG; tests/test_gpu_shortcuts.py)."""
     import torch
     import roborugby_amd as rr
-    assert args.gpus == 1 and args.policy == "random" and args.fuse == 1 and args.arenas % args.pipeline == 0
+    assert args.gpus == 1 and args.fuse == 1 and args.arenas % args.pipeline == 0
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     P, N, K, W = args.pipeline, args.arenas, args.steps, args.warmup
     n = N // P
-    envs = [rr.BatchedRoboRugbyEnv(n, preset=args.preset, device=dev, seed=0, time_limit=True, auto_reset=True, dtype=args.dtype,
-                                   arena_offset=i * n) for i in range(P)]
-    p = envs[0].preset
+    pipe = rr.ShardedPipeline(N, shards=P, device=dev, preset=args.preset, seed=0, time_limit=True, auto_reset=True, dtype=args.dtype)
+    p = pipe.preset
     na = p.nr
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234)
-    acts = torch.randint(0, 8, (K + W, N, na), generator=gen, device=dev, dtype=torch.int32)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(P)]
+    gens = [torch.Generator(device=dev) for _ in range(P)]
+    for i, g in enumerate(gens):
+        g.manual_seed(1234 + i)
+    acts = torch.randint(0, 8, (K + W, N, na), generator=gens[0], device=dev, dtype=torch.int32) if args.policy == "random" else None
     outs = [(torch.empty(n, 11, device=dev), torch.empty(n, device=dev), torch.empty(n, dtype=torch.uint8, device=dev),
              torch.empty(n, 11, device=dev) if p.nr_grumpy else None, torch.empty(n, device=dev),
              torch.empty(n, dtype=torch.int32, device=dev)) for _ in range(P)]
-    for e in envs:
-        e.reset()
-    torch.cuda.synchronize()
+    step_no = [0] * P
 
-    def run(k0, k1):
-        for s in range(k0, k1):
-            for i, e in enumerate(envs):
-                with torch.cuda.stream(streams[i]):
-                    e.step(acts[s, i * n:(i + 1) * n], out=outs[i])
+    def policy(i, obs):
+        s = step_no[i]
+        step_no[i] += 1
+        if acts is not None:
+            return acts[s, i * n:(i + 1) * n]
+        a1 = chase_actions(obs, 0.1, gens[i]).view(n, 1)
+        return torch.cat([a1, torch.randint(0, 8, (n, na - 1), generator=gens[i], device=dev, dtype=torch.int32)], 1) if na > 1 else a1
 
-    run(0, W)
+    pipe.reset()
     torch.cuda.synchronize()
-    cnt0 = sum(int(e.episode_stats()[3].sum().item()) for e in envs)
+    pipe.run(policy, W, outs=outs)
+    torch.cuda.synchronize()
+    cnt0 = sum(int(e.episode_stats()[3].sum().item()) for e in pipe.envs)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(W, W + K)
+    pipe.run(policy, K, outs=outs)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    cnt1 = sum(int(e.episode_stats()[3].sum().item()) for e in envs)
+    cnt1 = sum(int(e.episode_stats()[3].sum().item()) for e in pipe.envs)
     resets = cnt1 - cnt0 - sum(int(o[2].sum().item()) for o in outs)
     steps = N * K - max(resets, 0)
     bytes_per_step = p.algorithmic_bytes_per_step(na)
     achieved = bytes_per_step * steps / dt / 1e9
+    lanes = pipe.envs[0].lanes_per_env()
     line = {"metric": "env_steps_per_sec", "value": steps / dt, "unit": "env-steps/s", "n_gpus": 1, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"{N} parallel arenas per GPU as {P} independent shards of {n} on {P} HIP streams (launches of "
-                                   f"different shards overlap), SimpleDuel3 preset {args.preset}, random-policy rollout, {na} action(s)/arena, "
-                                   f"auto-reset on done, {envs[0].lanes_per_env()} lanes per arena",
-                       "arenas_per_gpu": N, "preset": args.preset, "policy": "random", "lanes_per_arena": envs[0].lanes_per_env(),
+                                   f"different shards overlap), SimpleDuel3 preset {args.preset}, {args.policy}-policy rollout, "
+                                   f"{na} action(s)/arena, auto-reset on done, {lanes} lanes per arena",
+                       "arenas_per_gpu": N, "preset": args.preset, "policy": args.policy, "lanes_per_arena": lanes,
                        "sharding": "single GPU", "steps_per_launch": 1, "pipeline": P},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "k_step", "kernel_ms": None,
-                         "algorithmic_bytes_per_env_step": bytes_per_step, "record_bytes_per_env": envs[0].state_bytes_per_env(),
+                         "algorithmic_bytes_per_env_step": bytes_per_step, "record_bytes_per_env": pipe.envs[0].state_bytes_per_env(),
                          "note": "overlapping launches: achieved = algorithmic bytes of all arenas per step / wall time per step"}}
     print(json.dumps(line), flush=True)
-    for e in envs:
-        e.close()
+    pipe.close()
 
 
 def main():

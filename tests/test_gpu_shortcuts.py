@@ -268,3 +268,31 @@ def test_shard_envs_on_two_streams_equal_one_batch():
     for k in ("robots", "balls", "robots_i"):
         x, y = a[k], torch.cat([b[0][k], b[1][k]])
         assert torch.equal(x.nan_to_num(7e77), y.nan_to_num(7e77)) if x.dtype.is_floating_point else torch.equal(x, y)
+
+
+def test_sharded_pipeline_with_a_policy_in_the_loop_equals_one_batch():
+    """roborugby_amd.ShardedPipeline: two actor groups, each with its own (deterministic, per-arena) policy call on its own
+    stream -- the trajectories are those of one batch stepped with the same policy."""
+    import roborugby_amd as rr
+    n, S = 8192, 40
+
+    def chase(obs):
+        dlt = (obs[:, 1] - obs[:, 0] + 540.0) % 360.0 - 180.0
+        return torch.where(dlt.abs() < 8, 0, torch.where(dlt > 0, 2, 3)).to(torch.int32)
+    whole = rr.BatchedRoboRugbyEnv(n, preset="T", seed=8)
+    obs = whole.reset()
+    rew = torch.zeros(n, device="cuda")
+    for s in range(S):
+        obs, r, d, _ = whole.step(chase(obs))
+        rew += r
+    pipe = rr.ShardedPipeline(n, shards=2, preset="T", seed=8)
+    pipe.reset()
+    rews = [torch.zeros(n // 2, device="cuda") for _ in range(2)]
+
+    def on_step(i, s, o, r, d, info):
+        rews[i] += r
+    last = pipe.run(lambda i, o: chase(o), S, on_step=on_step)
+    pipe.synchronize()
+    assert torch.equal(pipe.gather([l[0] for l in last]), obs) and torch.equal(pipe.gather(rews), rew)
+    a, b = whole.get_state(), [e.get_state() for e in pipe.envs]
+    assert torch.equal(a["balls"], torch.cat([b[0]["balls"], b[1]["balls"]]))
