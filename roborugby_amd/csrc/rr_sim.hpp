@@ -662,7 +662,13 @@ template <class C> RR_HD bool ball_near_robot(const Arena<C> &A, int b, int r) {
     const R ux = (q[2] - q[0]) * (R)0.05, uy = (q[3] - q[1]) * (R)0.05;     // TL -> TR, 20 long
     const R vx = (q[4] - q[0]) * (R)0.025, vy = (q[5] - q[1]) * (R)0.025;   // TL -> BL, 40 long
     const R lx = dx * ux + dy * uy, ly = dx * vx + dy * vy;
-    return (m_abs(lx) <= (R)17.05) & (m_abs(ly) <= (R)27.05);
+    // Beyond BOTH side lines (the four 7 x 7 squares off the corners) no diameter reaches a side segment -- the one parallel
+    // to a side passes it outside its end points, the other is parallel to the other side -- so only that corner's radius test
+    // can hit there: within 7 of the corner.  This is where a ball pushed by a corner comes to rest (7.2-7.8 px from it), and it
+    // used to send every sub-step of such an arena through the narrow phase twice.
+    const R ax = m_abs(lx), ay = m_abs(ly), cx = ax - (R)10, cy = ay - (R)20;
+    const bool corner_zone = (cx > (R)0.05) & (cy > (R)0.05);
+    return (ax <= (R)17.05) & (ay <= (R)27.05) & (!corner_zone | (cx * cx + cy * cy <= (R)(7.05 * 7.05)));
 }
 
 // Third exact cull, robot against robot: separating-axis test of the two 20 x 40 rectangles.  robots_collided hits only if

@@ -50,3 +50,29 @@ def oracle_step(preset, robots_xyr, balls_xyv, actions):
     o.set_clean_state(robots_xyr, balls_xyv)
     res = o.step(actions)
     return res, o.get_state()
+
+
+def make_corner_states(preset, n, seed):
+    """Balls around robot corners: at 6.4-7.7 px from a corner, in and next to the 7 x 7 square beyond BOTH side lines where only
+    the corner's radius test can hit (rr_sim.hpp: ball_near_robot's corner-zone bound) -- touching, grazing and just clear."""
+    cfg = ol.PRESETS[preset]
+    nr, nb = cfg["nr_h"] + cfg["nr_g"], cfg["nb_p"] + cfg["nb_n"]
+    W, H = cfg["W"], cfg["H"]
+    rng = np.random.RandomState(seed)
+    robots = np.zeros((n, nr, 3))
+    balls = np.zeros((n, nb, 4))
+    for a in range(n):
+        for r in range(nr):
+            robots[a, r] = [rng.uniform(80, W - 80), rng.uniform(80, H - 80),
+                            rng.choice([0, 90, 180, 270, rng.uniform(0, 360), float(rng.randint(0, 361))])]
+        for b in range(nb):
+            r = rng.randint(nr)
+            rot = np.radians(robots[a, r, 2])
+            ux, uy, vx, vy = np.cos(rot), -np.sin(rot), np.sin(rot), np.cos(rot)  # the 20-px and the 40-px axis on the screen (y down)
+            sx, sy = rng.choice([-1, 1]), rng.choice([-1, 1])
+            d, th = rng.uniform(6.4, 7.7), rng.uniform(-0.25, np.pi / 2 + 0.25)   # mostly outward of both sides, some just across
+            lx, ly = sx * (10 + d * np.cos(th)), sy * (20 + d * np.sin(th))
+            balls[a, b, :2] = robots[a, r, :2] + lx * np.array([ux, uy]) + ly * np.array([vx, vy])
+            balls[a, b, 2:] = rng.choice([0.0, 0.0, 1.0]) * rng.uniform(-1.5, 1.5, 2)
+    actions = rng.randint(0, 8, (n, nr)).astype(np.int32)
+    return robots, balls, actions

@@ -64,12 +64,30 @@ def test_emulated_kernel_vs_oracle_on_adversarial_states(preset, n, narrow):
           f"{knife} on a knife edge of the reference itself")
 
 
+@pytest.mark.parametrize("preset,n,narrow", [("T", 900, False), ("G", 160, False), ("G", 120, True)])
+def test_emulated_kernel_vs_oracle_on_balls_around_robot_corners(preset, n, narrow):
+    """the broad phase's corner-zone bound (ball_near_robot) must not drop a hit: balls at 6.4-7.7 px from robot corners"""
+    robots, balls, actions = adv.make_corner_states(preset, n, seed=3 + int(narrow))
+    env = el.EmuEnv(preset, narrow=narrow)
+    ok = knife = contacts = 0
+    for a in range(n):
+        res, st = adv.oracle_step(preset, robots[a], balls[a], actions[a])
+        env.set_poses(robots[a], balls[a])
+        r_res = env.step(actions[a])
+        v = _compare(preset, res, st, r_res, env.get_state(), (preset, a), (robots[a], balls[a], actions[a]))
+        ok += v == "ok"
+        knife += v == "knife"
+        if v == "ok":
+            contacts += int(np.abs(st["balls"][:, 6:] - balls[a][:, 2:] * 0.995 ** 12).max() > 1e-6)
+    assert ok > 0.8 * n and contacts > 0.15 * n and knife <= 0.03 * n, (ok, knife, contacts)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("preset,n", [("T", 6000), ("G", 3000)])
-def test_gpu_kernel_vs_oracle_on_adversarial_states(preset, n):
+@pytest.mark.parametrize("preset,n,gen", [("T", 6000, "mixed"), ("G", 3000, "mixed"), ("T", 5000, "corners"), ("G", 1500, "corners")])
+def test_gpu_kernel_vs_oracle_on_adversarial_states(preset, n, gen):
     import torch
     import roborugby_amd as rr
-    robots, balls, actions = adv.make_states(preset, n, seed=5)
+    robots, balls, actions = (adv.make_states if gen == "mixed" else adv.make_corner_states)(preset, n, seed=5)
     env = rr.BatchedRoboRugbyEnv(n, preset=preset, time_limit=False, auto_reset=False)
     env.set_poses(robots, balls)
     o, r, d, info = env.step_f64(torch.as_tensor(actions))
