@@ -301,6 +301,18 @@ template <typename R> RR_HD bool within(V2<R> p, Seg<R> l, R buf) {
     const bool wy = ((l.a.y - buf <= p.y) & (p.y <= l.b.y + buf)) | ((l.b.y - buf <= p.y) & (p.y <= l.a.y + buf));
     return wx & wy;
 }
+// Can `within(q, s, 0) & within(q, d, buf)` hold for ANY point q?  Only if the two accepted boxes meet -- the very bounds within()
+// compares against (rounded the same way), so a "no" here is the conjunction's "no" whatever the intersection point is, inf and
+// NaN included.  The contact paths of the narrow virtual waves (fewer than eight lanes per arena: a lane sweeps several candidates one
+// after the other) use it to skip the two divisions of a candidate that cannot hit -- a ball touches one side with one diameter,
+// seven of the eight (side, diameter) candidates stop here: T +2.5 %, T chase +7 %.  With eight lanes and more every candidate
+// has its own lane, the division runs anyway for the one that can hit, and the test only adds instructions (G chase -3 %).
+template <typename R> RR_HD bool boxes_meet(Seg<R> s, Seg<R> d, R buf) {
+    const R sx0 = py_min<R>(s.a.x, s.b.x), sx1 = py_max<R>(s.a.x, s.b.x), sy0 = py_min<R>(s.a.y, s.b.y), sy1 = py_max<R>(s.a.y, s.b.y);
+    const R dx0 = py_min<R>(d.a.x - buf, d.b.x - buf), dx1 = py_max<R>(d.a.x + buf, d.b.x + buf);
+    const R dy0 = py_min<R>(d.a.y - buf, d.b.y - buf), dy1 = py_max<R>(d.a.y + buf, d.b.y + buf);
+    return (sx0 <= dx1) & (dx0 <= sx1) & (sy0 <= dy1) & (dy0 <= sy1);
+}
 // MyUtils.py:97-110
 template <typename R> RR_HD R angle_degrees(V2<R> a, V2<R> b, int &st) {
     R dy = b.y - a.y, dx = b.x - a.x;
@@ -815,9 +827,9 @@ template <class C, bool CACHED> RR_HD uint32_t detect_ball_robot(Arena<C> &A, co
                         ox = d == 0 ? iq[0] : iq[2]; oy = d == 0 ? iq[1] : iq[3];
                     }
                     Seg<R> dia = { { bc.x + ox, bc.y + oy }, { bc.x + -ox, bc.y + -oy } };
+                    Seg<R> side = robot_side(A, r, sd);
                     R md, cd, ms, cs;
                     slope_yint<R>(dia.a, dia.b, md, cd, st);
-                    Seg<R> side = robot_side(A, r, sd);
                     if (CACHED) { ms = A.sm[r][sd]; cs = A.sc[r][sd]; }
                     else slope_yint<R>(side.a, side.b, ms, cs, st);
                     V2<R> q = intersect_mb<R>(ms, cs, side.a.x, md, cd, dia.a.x);
@@ -851,15 +863,22 @@ template <class C, bool CACHED> RR_HD uint32_t detect_ball_robot(Arena<C> &A, co
                     ox = d == 0 ? iq[0] : iq[2]; oy = d == 0 ? iq[1] : iq[3];
                 }
                 Seg<R> dia = { { bc.x + ox, bc.y + oy }, { bc.x + -ox, bc.y + -oy } };
-                R md, cd;
-                slope_yint<R>(dia.a, dia.b, md, cd, st);
-                for (int sd = 0; sd < 4; sd++) {
-                    Seg<R> side = robot_side(A, r, sd);
-                    R ms, cs;
-                    if (CACHED) { ms = A.sm[r][sd]; cs = A.sc[r][sd]; }
-                    else slope_yint<R>(side.a, side.b, ms, cs, st);
-                    V2<R> q = intersect_mb<R>(ms, cs, side.a.x, md, cd, dia.a.x);
-                    hit = hit | (within<R>(q, side, (R)0) & within<R>(q, dia, (R)0));
+                bool need[4], any_need = false;
+                for (int sd = 0; sd < 4; sd++) { need[sd] = boxes_meet<R>(robot_side(A, r, sd), dia, (R)0); any_need = any_need | need[sd]; }
+                if (any_need) {
+                    R md, cd;
+                    slope_yint<R>(dia.a, dia.b, md, cd, st);
+#pragma unroll
+                    for (int sd = 0; sd < 4; sd++) {
+                        if (need[sd]) {
+                            Seg<R> side = robot_side(A, r, sd);
+                            R ms, cs;
+                            if (CACHED) { ms = A.sm[r][sd]; cs = A.sc[r][sd]; }
+                            else slope_yint<R>(side.a, side.b, ms, cs, st);
+                            V2<R> q = intersect_mb<R>(ms, cs, side.a.x, md, cd, dia.a.x);
+                            hit = hit | (within<R>(q, side, (R)0) & within<R>(q, dia, (R)0));
+                        }
+                    }
                 }
             }
             RR_VOTE(m, l, hit);
@@ -1012,10 +1031,12 @@ RR_HD int first_surface_hit(Arena<C> &A, int r, const Seg<typename C::Real> dia[
                 int st = 0;
                 Seg<R> side = robot_side(A, r, sd);
                 const Seg<R> di = pick_dia<R>(dia, d);
-                R md, cd;
-                slope_yint<R>(di.a, di.b, md, cd, st);
-                V2<R> I = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, md, cd, di.a.x); // cached side slope
-                hit = within<R>(I, side, (R)0) & within<R>(I, di, buf);
+                if (C::VW >= 8 || boxes_meet<R>(side, di, buf)) { // (the pre-test pays where a lane sweeps several candidates)
+                    R md, cd;
+                    slope_yint<R>(di.a, di.b, md, cd, st);
+                    V2<R> I = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, md, cd, di.a.x); // cached side slope
+                    hit = within<R>(I, side, (R)0) & within<R>(I, di, buf);
+                }
             }
             RR_VOTE(m, l, hit);
         }
@@ -1042,12 +1063,14 @@ RR_HD void first_surface_hit2(Arena<C> &A, int r, const Seg<typename C::Real> di
                 int st = 0;
                 Seg<R> side = robot_side(A, r, sd);
                 const Seg<R> di = pick_dia<R>(dia, d);
-                R md, cd;
-                slope_yint<R>(di.a, di.b, md, cd, st);
-                V2<R> I = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, md, cd, di.a.x);
-                const bool ws = within<R>(I, side, (R)0);
-                hita = ws & within<R>(I, di, bufa);
-                hitb = ws & within<R>(I, di, bufb);
+                if (C::VW >= 8 || boxes_meet<R>(side, di, py_max<R>(bufa, bufb))) { // (the larger buffer's box contains the smaller one's)
+                    R md, cd;
+                    slope_yint<R>(di.a, di.b, md, cd, st);
+                    V2<R> I = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, md, cd, di.a.x);
+                    const bool ws = within<R>(I, side, (R)0);
+                    hita = ws & within<R>(I, di, bufa);
+                    hitb = ws & within<R>(I, di, bufb);
+                }
             }
             RR_VOTE(ma, l, hita);
             RR_VOTE(mb, l, hitb);
