@@ -153,3 +153,29 @@ def test_config5_learns_to_beat_the_random_policy():
           f"training {res['env_steps_per_sec'] / 1e6:.1f} M env-steps/s, greedy rollout {res['rollout_env_steps_per_sec_greedy_policy'] / 1e6:.1f} M")
     assert abs(rand) < 1000 and best > rand + 1500
     assert res["epsilon"] == 0.2 and res["learn_calls"] == 599 * 4
+
+
+def test_wide_batch_linear_has_the_gradients_of_a_plain_linear():
+    """the learn step's split weight-gradient GEMM (dqn._WideBatchLinear): same forward, same gradients up to summation order"""
+    import torch
+    from roborugby_amd import dqn
+    torch.manual_seed(0)
+    net_a = dqn.DeepQNetwork(5e-4, 11, 256, 256, 8).double()
+    net_b = dqn.DeepQNetwork(5e-4, 11, 256, 256, 8).double()
+    net_b.load_state_dict(net_a.state_dict())
+    x = torch.randn(8192, 11, dtype=torch.float64)
+    act = torch.randint(0, 8, (8192, 1))
+    tgt = torch.randn(8192, dtype=torch.float64)
+
+    def loss_of(net, plain):
+        if plain:
+            h = torch.relu(net.fc1(x)); h = torch.relu(net.fc2(h)); q = net.fc3(h)
+        else:
+            q = dqn._linear(net.fc3, torch.relu(dqn._linear(net.fc2, torch.relu(dqn._linear(net.fc1, x)))))
+        return ((q.gather(1, act).squeeze(1) - tgt) ** 2).mean()
+    la, lb = loss_of(net_a, True), loss_of(net_b, False)
+    assert torch.equal(la, lb)
+    la.backward(); lb.backward()
+    for (n, pa), (_, pb) in zip(net_a.named_parameters(), net_b.named_parameters()):
+        assert torch.allclose(pa.grad, pb.grad, rtol=1e-10, atol=1e-13), n
+    assert dqn._linear(net_a.fc1, x[:100]).shape == (100, 256)  # narrow batches take the plain layer
