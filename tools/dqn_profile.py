@@ -6,7 +6,7 @@ import roborugby_amd as rr
 from roborugby_amd.dqn import BatchedDQNAgent
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 env = rr.make("RoboRugbySimpleDuel-v3", num_envs=n, preset="T", device="cuda:0")
-agent = BatchedDQNAgent(batch_size=300 * 8 + 100, device="cuda:0", max_mem_size=max(500000, 8 * n))
+agent = BatchedDQNAgent(batch_size=min(32768, max(2500, n // 2)), device="cuda:0", max_mem_size=max(500000, 32 * n))  # train()'s defaults
 obs = env.reset()
 acc = {}
 def timed(name, fn):
@@ -19,6 +19,6 @@ for i in range(140):
     o2, r, d, info = timed("env.step", lambda: env.step(a.view(-1, 1)))
     real = (info.status & 1024) == 0
     timed("store", lambda: agent.store_transition(obs, a, r, o2, d, valid=real))
-    timed("learn", lambda: agent.learn())
+    timed("learn x4", lambda: [agent.learn() for _ in range(4)])
     obs = o2
 for k, v in acc.items(): print(f"{k:14s} {v / 100 * 1e3:8.3f} ms/step")
