@@ -39,6 +39,12 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=1, help="extension, not the headline: the arenas as P independent shard envs "
                     "(arena_offset) stepped on P HIP streams, so that consecutive launches of different shards overlap and the chip "
                     "does not drain at the end of every step; random policy, one GPU")
+    ap.add_argument("--budget", type=int, default=0, help="extension, not the headline: the budgeted step (rr_config.step_budget_clocks, "
+                    "shader clocks): an arena over the budget after an expensive sub-step parks and reports NOT_READY; such rows are "
+                    "NOT counted as env steps")
+    ap.add_argument("--no-stagger", action="store_true", help="time the steps right after a fresh reset (every arena at the same, "
+                    "contact-poor episode phase).  Default: arenas at uniformly random episode phases, reached by a pre-roll of "
+                    "one whole episode outside the timed region -- the steady state of a long rollout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -84,6 +90,27 @@ def cpu_baseline(preset, seconds):
             "sample": f"{cores} threads x {arenas} arenas x {steps} steps of preset {preset}, random actions from "
                       f"reset, fp64 C oracle (bit-exact to the Python reference on tests/golden); {dt:.1f} s wall",
             "single_core_value": rate1}
+
+
+def hbm_copy_probe(dev, mib=1024, iters=20):
+    """what a plain device-to-device copy reaches on THIS chip (read + write bytes / HIP-event time),
+    quoted next to the 8 TB/s spec as roofline.peak_measured.  One GiB source, one GiB destination, far beyond the 256 MB of
+    Infinity Cache; a few milliseconds in total, outside the timed region."""
+    import torch
+    n = mib * 1024 * 1024 // 4
+    src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    del src, dst
+    return 2.0 * n * 4 / (ms * 1e-3) / 1e9
 
 
 def chase_actions(obs, noise, gen):
@@ -175,7 +202,7 @@ def main():
     dev = torch.device(f"cuda:{local_dev}")
     n = args.arenas
     env = rr.BatchedRoboRugbyEnv(n, preset=args.preset, device=dev, seed=0, time_limit=True, auto_reset=True,
-                                 dtype=args.dtype, arena_offset=rrd.shard_offset(rank, n))
+                                 dtype=args.dtype, arena_offset=rrd.shard_offset(rank, n), step_budget_clocks=args.budget)
     p = env.preset
     na = p.nr
     obs = env.reset()
@@ -198,6 +225,22 @@ def main():
                 if na > 1 else a1
         return env.step(a, out=out)
 
+    stagger = not args.no_stagger and args.fuse == 1
+    if stagger:
+        # Steady state: every arena at a uniformly random phase of its episode, with the state a rollout of that length leaves
+        # (contacts accumulate late in an episode: robots park balls against walls).  The step counters are spread over
+        # [0, T) and ONE whole episode is rolled outside the timed region, so each arena has been re-placed at its own time.
+        st = env.get_state()
+        T = p.game_len_steps
+        phase = torch.randint(0, T, (n,), generator=gen, device=dev, dtype=torch.int32)
+        env.set_state(st["robots"], st["robots_i"], st["balls"], phase)
+        pre = torch.randint(0, 8, (min(T, 512), n, na), generator=gen, device=dev, dtype=torch.int32)
+        for i in range(T + 1):
+            if args.policy == "random":
+                env.step(pre[i % pre.shape[0]], out=out)
+            else:
+                one_step(1)
+        del pre
     F = max(1, args.fuse)
     if F > 1:
         assert args.policy == "random" and K % F == 0 and W % F == 0, "--fuse needs the random policy and K, W multiples of it"
@@ -215,7 +258,10 @@ def main():
     rrd.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    resets_seen = 0
+    # the ONE collective of the path: finished-episode returns, all-gathered for logging every min(log_interval, K) steps
+    # (the driver runs --steps 20: with the default interval of 25 the loop alone would never issue it)
+    gather_every = max(F, min(args.log_interval, K) // F * F)
+    not_ready = torch.zeros(n, dtype=torch.int32, device=dev)
     for i in range(0, K, F):
         ev[i][0].record()
         if F > 1:
@@ -225,12 +271,17 @@ def main():
         else:
             one_step(W + i)
         ev[i][1].record()
-        if world > 1 and (i + 1) % args.log_interval == 0:
+        if args.budget:
+            not_ready += (out[5] >> 14) & 1  # parked arenas of this call: not env steps
+        if world > 1 and (i + F) % gather_every == 0:
             lr = env.episode_stats()[0]
             pending.append(rrd.all_gather_returns(lr, async_op=True))
+    if world > 1:  # and once after the loop: the returns of the episodes that ended since the last interval
+        pending.append(rrd.all_gather_returns(env.episode_stats()[0], async_op=True))
     for _, work in pending:
         if work is not None:
             work.wait()
+    gathered_rows = [int(t.shape[0]) for t, _ in pending]
     torch.cuda.synchronize()
     rrd.barrier()
     dt = time.perf_counter() - t0
@@ -239,22 +290,30 @@ def main():
     _, _, _, cnt1 = env.episode_stats()
     last_done = fout[2][-1] if F > 1 else out[2]  # arenas that finished in the very last step are re-placed by a later call
     resets = int((cnt1 - cnt0).sum().item()) - int(last_done.sum().item())
-    local_steps = n * K - max(resets, 0)
+    n_not_ready = int(not_ready.sum().item())
+    local_steps = n * K - max(resets, 0) - n_not_ready
     total_steps = rrd.reduce_sum(float(local_steps), dev)
     kern_ms = sum(ev[i][0].elapsed_time(ev[i][1]) for i in range(0, K, F)) / (K // F)  # per launch
     kern_ms = rrd.reduce_max(kern_ms, dev)
-    status_bits = int(torch.bitwise_and((fout if F > 1 else out)[5], 0xFFFF & ~1024 & ~256).max().item())
+    status_bits = int(torch.bitwise_and((fout if F > 1 else out)[5], 0xFFFF & ~1024 & ~256 & ~16384).max().item())
 
     if rank == 0:
         bytes_per_step = p.algorithmic_bytes_per_step(na)            # G 601 B, T 149 B
         achieved = bytes_per_step * n * F / (kern_ms * 1e-3) / 1e9     # GB/s, one launch = n * F arena-steps
-        traffic = None
+        traffic, traffic_source = None, None
         tfile = os.path.join(REPO, "profiles", "traffic.json")          # PMC-derived HBM bytes per launch, if measured
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(f"{args.preset}_{args.dtype}_{n}")
+                ent = json.load(open(tfile)).get(f"{args.preset}_{args.dtype}_{n}")
+                if isinstance(ent, dict):
+                    traffic, traffic_source = ent.get("bytes"), ent.get("source")
+                elif ent is not None:
+                    traffic, traffic_source = ent, "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
             except Exception:
                 traffic = None
+        if traffic_source:
+            traffic_source += "; a constant from that profiling run, not measured by this bench run"
+        peak_measured = hbm_copy_probe(dev)
         line = {
             "metric": "env_steps_per_sec", "value": total_steps / dt, "unit": "env-steps/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -262,13 +321,22 @@ def main():
             "config": {"workload": f"{n} parallel arenas per GPU, SimpleDuel3 preset {args.preset} "
                                    f"({p.nr_happy}+{p.nr_grumpy} robots, {p.nb_pos}+{p.nb_neg} balls, "
                                    f"{int(p.arena_w)}x{int(p.arena_h)}), {args.policy}-policy rollout, {na} action(s)/arena, "
-                                   f"auto-reset on done, {env.lanes_per_env()} lanes per arena ({64 // env.lanes_per_env()} arena(s) per wavefront)",
+                                   f"auto-reset on done, {env.lanes_per_env()} lanes per arena ({64 // env.lanes_per_env()} arena(s) per wavefront)"
+                                   + (", arenas at uniformly random episode phases (pre-roll of one whole episode outside the timed region)"
+                                      if stagger else ", timed right after a fresh reset")
+                                   + (f", BUDGETED step ({args.budget} clocks): {n_not_ready} NOT_READY rows not counted" if args.budget else ""),
                        "arenas_per_gpu": n, "preset": args.preset, "policy": args.policy, "lanes_per_arena": env.lanes_per_env(),
                        "sharding": f"dp{world} (independent arena shards, returns all-gathered every "
-                                   f"{args.log_interval} steps)" if world > 1 else "single GPU",
-                       "steps_per_launch": F, "fault_status_bits_seen": status_bits},
+                                   f"{gather_every} steps and once after the loop)" if world > 1 else "single GPU",
+                       "steps_per_launch": F, "fault_status_bits_seen": status_bits, "staggered_phases": bool(stagger),
+                       "step_budget_clocks": args.budget, "not_ready_fraction": n_not_ready / float(n * K),
+                       "collectives": {"all_gather_calls": len(pending), "ranks": world, "backend": rrd.backend_name(),
+                                       "bytes_per_rank": 4 * n, "gathered_rows": gathered_rows[-1] if gathered_rows else 0,
+                                       "every_steps": gather_every} if world > 1 else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "peak_measured": peak_measured,
+                         "peak_measured_how": "device-to-device copy of 1 GiB (torch copy_, read + write bytes / HIP-event time), this run",
                          "kernel": "k_step", "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": bytes_per_step,
                          "record_bytes_per_env": env.state_bytes_per_env(),
                          "note": "latency/VALU-bound by construction: 12 dependent sub-steps of fp64 geometry per "

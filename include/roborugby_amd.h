@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RR_ABI_VERSION 3
+#define RR_ABI_VERSION 4
 
 /* per-arena status bits; each mirrors one exception site of the reference */
 #define RR_STATUS_BOT_RESOLVE_FAIL 1   /* RR_EnvBase.py:313  "UNABLE TO RESOLVE BOT/BOT COLLISIONS"   */
@@ -37,6 +37,7 @@ extern "C" {
 #define RR_STATUS_UNDO_WARN 256        /* RR_EnvBase.py:419  GAME_MODE warning, step continued        */
 #define RR_STATUS_RESET_GAVE_UP 512    /* spawn rejection sampling hit its attempt cap                */
 #define RR_STATUS_WAS_RESET 1024       /* this call reset the arena instead of stepping it            */
+#define RR_STATUS_NOT_READY 16384       /* budgeted step only: this arena's step is still in progress (see step_budget_clocks) */
 #define RR_STATUS_FLAG_MASK 0xFFFF     /* bits 0-15 are the flags above ...                            */
 #define RR_STATUS_NAUGHTY_SHIFT 16     /* ... bits 16+r: robot r joined NaughtyBots' set this step (RR_ScoreKeepers.py:123-128) */
 
@@ -68,6 +69,15 @@ typedef struct rr_config {
     int32_t device;         /* HIP device ordinal                                                      */
     uint64_t seed;          /* keys the counter-based reset RNG                                        */
     uint64_t arena_offset;  /* global id of local arena 0: makes results invariant to sharding         */
+    uint32_t step_budget_clocks; /* 0 (default): every rr_step call completes every arena's step -- the reference's semantics
+                               (RR_EnvBase.py:260-297), and the call lasts as long as its slowest arena.  > 0: the BUDGETED step,
+                               an opt-in extension for contact-rich policies: an arena whose wavefront has run for more than this
+                               many shader clocks at the end of an expensive physics sub-step (RR_EnvBase.py:275-287 runs 12 per
+                               step) parks there; the call reports RR_STATUS_NOT_READY for it -- reward 0, done 0, its obs / obs_g
+                               rows NOT written (reuse the buffers to keep the previous ones) -- and the next call resumes it where
+                               it stopped, IGNORING the action it is given.  Each arena's trajectory as a function of the actions
+                               it accepted is bit-identical to step_budget_clocks = 0.  SimpleDuel3's own reward stack only. */
+    uint32_t reserved_;     /* 0                                                                       */
 } rr_config;
 
 int rr_abi_version(void);
@@ -92,6 +102,9 @@ int rr_step(rr_env *env, const int32_t *actions, int32_t na, float *obs, float *
 /* Same step with fp64 outputs (full-precision parity checks). */
 int rr_step_f64(rr_env *env, const int32_t *actions, int32_t na, double *obs, double *reward, uint8_t *done,
                 double *obs_g, double *reward_g, int32_t *status, void *stream);
+/* Changes rr_config.step_budget_clocks of a live handle (host-side; takes effect with the next rr_step).  0 switches parking
+ * off -- arenas that are parked at that moment finish their step in the next call(s) as usual. */
+int rr_set_step_budget(rr_env *env, uint32_t clocks);
 /* Open-loop rollout: nsteps consecutive rr_step calls per arena in ONE launch -- the record stays in LDS, and no arena
  * waits for the slowest arena of the batch between steps (a launch per step ends when its slowest wavefront does).
  * actions [nsteps, N, na] (repeat == 0) or [N, na] applied at every step (repeat != 0: the action-repeat / frame-skip
@@ -106,6 +119,9 @@ int rr_rollout(rr_env *env, const int32_t *actions, int32_t na, int32_t nsteps, 
  * rounded half-to-even like Python's round() (RR_Robot.py:100-102). */
 int rr_step_thrust(rr_env *env, const float *thrust, int32_t nk, float *obs, float *reward, uint8_t *done,
                    float *obs_g, float *reward_g, int32_t *status, void *stream);
+/* Same entry with fp64 outputs (the thrust entry's observation / reward parity checks; RR_DTYPE_F64 handles only). */
+int rr_step_thrust_f64(rr_env *env, const float *thrust, int32_t nk, double *obs, double *reward, uint8_t *done,
+                       double *obs_g, double *reward_g, int32_t *status, void *stream);
 
 /* get_game_state(int_team=team) (RR_Observers.py:301-406) of the current state; robot_idx/ball_idx
  * = -1 selects the team's first robot / positive ball 0 like the reference defaults. */

@@ -23,6 +23,7 @@ class RRConfig(C.Structure):
         ("reset_on_fault", C.c_int32),
         ("dtype", C.c_int32), ("device", C.c_int32),
         ("seed", C.c_uint64), ("arena_offset", C.c_uint64),
+        ("step_budget_clocks", C.c_uint32), ("reserved_", C.c_uint32),
     ]
 
 
@@ -36,7 +37,9 @@ SYMBOLS = {
     "rr_reset": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "rr_step": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rr_step_f64": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rr_set_step_budget": (C.c_int, [_vp, C.c_uint32]),
     "rr_step_thrust": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rr_step_thrust_f64": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rr_rollout": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rr_observe": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
     "rr_observe_f64": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),

@@ -68,9 +68,6 @@ template <class C> constexpr int lds_waves_per_simd() {
 #ifdef RR_FORCE_WAVES // occupancy experiments only (tools/kernel_resources.py ... -DRR_FORCE_WAVES=3)
     return RR_FORCE_WAVES;
 #endif
-#ifdef RR_FORCE_WAVES // occupancy experiments only (tools/kernel_resources.py ... -DRR_FORCE_WAVES=3)
-    return RR_FORCE_WAVES;
-#endif
     constexpr int per_cu = (160 * 1024) / (int)(sizeof(Arena<C>) * arenas_per_block<C>()) * WAVES_PER_BLOCK;
     return per_cu / 4 < 1 ? 1 : (per_cu / 4 > RR_MIN_WAVES_PER_SIMD ? RR_MIN_WAVES_PER_SIMD : per_cu / 4);
 }
@@ -78,13 +75,16 @@ template <class C> constexpr int lds_waves_per_simd() {
 
 // MULTI = false: rr_step, one step per launch (nsteps, repeat unused); true: rr_rollout's loop over nsteps.  Separate
 // instantiations: the loop around step_arena costs the single-step kernel 12 % (measured) through register allocation alone.
-template <class C, typename O, bool MULTI>
+// BUDGET = true: the budgeted step (rr_sim.hpp: ParkCtx) -- a separate instantiation, so the default kernel carries none of it.
+template <class C, typename O, bool MULTI, bool BUDGET = false>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void k_step(SimParams<typename C::Real> sp, typename C::Real *recs,
                                                               int32_t *irecs, int n, const int32_t *actions,
                                                               const float *thrust, int na, O *obs, O *reward,
                                                               uint8_t *done, O *obs_g, O *reward_g, int32_t *status,
                                                               const uint32_t *order, uint32_t *cost, int nsteps, int repeat,
-                                                              uint32_t *snap, int32_t *isnap) {
+                                                              uint32_t *snap, int32_t *isnap, uint32_t *park = nullptr,
+                                                              uint32_t budget = 0) {
+    static_assert(!(MULTI && BUDGET), "rr_rollout keeps the record in LDS across steps: no barrier to budget");
 #ifdef RR_FAKE_LDS_ARENAS // resource experiments only (never run): what the register allocator does when LDS stops capping the occupancy
     __shared__ Arena<C> lds[RR_FAKE_LDS_ARENAS];
 #else
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
     if (wave >= arenas_per_block<C>()) return;
 #endif
     // slowest-first dispatch: workgroup b steps the group of arenas that was the b-th slowest in the previous step
-    const unsigned long long t_begin = cost ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long t_begin = (cost || BUDGET) ? __builtin_amdgcn_s_memtime() : 0ull;
     const int group = order ? (int)order[blockIdx.x] : (int)blockIdx.x;
     const int arena = group * arenas_per_block<C>() + wave;
     if (arena >= n) return; // uniform per virtual wave; no workgroup barrier is ever used
@@ -112,8 +112,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
     if constexpr (!MULTI) {
         StepOut<O> o = { obs, obs_g, reward, reward_g, done, status, sp.memo ? snap : nullptr, isnap, arena,
                          (int)Arena<C>::SNAP_WORDS, (int)Arena<C>::ISNAP_WORDS };
-        step_arena<C, O>(A, sp, sp.arena_offset + (uint64_t)arena, actions ? actions + (size_t)arena * na : nullptr,
-                         thrust ? thrust + (size_t)arena * 2 * na : nullptr, na, o);
+        if constexpr (BUDGET) {
+            ParkCtx pk;
+            pk.buf = park + (size_t)arena * Arena<C>::PARK_WORDS; pk.budget = budget; pk.t_begin = t_begin;
+            step_arena<C, O, true>(A, sp, sp.arena_offset + (uint64_t)arena, actions ? actions + (size_t)arena * na : nullptr,
+                                   thrust ? thrust + (size_t)arena * 2 * na : nullptr, na, o, pk);
+        } else {
+            step_arena<C, O>(A, sp, sp.arena_offset + (uint64_t)arena, actions ? actions + (size_t)arena * na : nullptr,
+                             thrust ? thrust + (size_t)arena * 2 * na : nullptr, na, o);
+        }
     } else {
         // nsteps consecutive GameEnv.step calls on the record held in LDS (rr_rollout): step s reads its actions at
         // [s][arena] (or the same ones again when `repeat`) and writes its outputs at [s][arena]
@@ -441,6 +448,8 @@ struct rr_env {
     uint32_t *order;     // slowest-first dispatch order of the arena groups (null: index order)
     uint32_t *cost;      // last step's duration per group
     int ngroups;
+    uint32_t *park;      // parked mid-step state of the budgeted step (null until a budget is first set)
+    uint32_t budget;     // shader clocks; 0xFFFFFFFF = "no budget, but parked arenas may exist" (after the budget was switched off)
 };
 
 static thread_local std::string g_err;
@@ -519,6 +528,7 @@ int rr_create(const rr_config *cfg, rr_env **out) {
     e->vw = 0;
     e->prog.n = 3; e->prog.id[0] = KEEPER_NAUGHTY; e->prog.id[1] = KEEPER_CHASE; e->prog.id[2] = KEEPER_PUSHPOS;
     e->custom_prog = false; e->track_prior = false; e->xs = nullptr; e->status_buf = nullptr; e->gs = nullptr;
+    e->park = nullptr; e->budget = 0;
     const char *want = getenv("RR_VW");
     const int want_vw = want ? atoi(want) : 0;
 #define X(kind_, a, b, c, d, R_, vw_) \
@@ -587,6 +597,9 @@ int rr_create(const rr_config *cfg, rr_env **out) {
         delete e;
         return fail(-2, std::string("rr_create: init kernel: ") + hipGetErrorString(he));
     }
+    if (cfg->step_budget_clocks) {
+        if (int rc = rr_set_step_budget(e, cfg->step_budget_clocks)) { rr_destroy(e); return rc; }
+    }
     *out = e;
     return 0;
 }
@@ -602,6 +615,7 @@ int rr_destroy(rr_env *e) {
     if (e->status_buf) (void)hipFree(e->status_buf);
     if (e->order) (void)hipFree(e->order);
     if (e->cost) (void)hipFree(e->cost);
+    if (e->park) (void)hipFree(e->park);
     delete e;
     return 0;
 }
@@ -642,6 +656,9 @@ static int step_impl(rr_env *e, const int32_t *actions, const float *thrust, int
     DeviceGuard guard(e->cfg.device);
     hipStream_t s = (hipStream_t)stream;
     if ((e->custom_prog || e->track_prior || e->gs) && !status) status = e->status_buf; // the side kernels need the NaughtyBots / WAS_RESET bits
+    if (e->park && (e->custom_prog || e->track_prior || e->gs))
+        return fail(-1, "step budget: SimpleDuel3's own reward stack only (the side kernels of a custom reward program / prior-step "
+                        "tracking / goal scoring bracket whole steps)");
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
         if constexpr (std::is_same<O, double>::value && !std::is_same<RR, double>::value) {
@@ -649,7 +666,11 @@ static int step_impl(rr_env *e, const int32_t *actions, const float *thrust, int
         } else {
             if (e->custom_prog || e->track_prior)
                 hipLaunchKernelGGL((k_extras_begin<CC>), dim3((n + 127) / 128), dim3(128), 0, s, (const RR *)e->recs, n, (RR *)e->xs, (const uint8_t *)nullptr);
-            if (nsteps == 1)
+            if (nsteps == 1 && e->park)
+                hipLaunchKernelGGL((k_step<CC, O, false, true>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (RR *)e->recs, e->irecs, n,
+                                   actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status, (const uint32_t *)e->order, e->cost,
+                                   1, 0, e->snap, e->isnap, e->park, e->budget);
+            else if (nsteps == 1)
                 hipLaunchKernelGGL((k_step<CC, O, false>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (RR *)e->recs, e->irecs, n,
                                    actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status, (const uint32_t *)e->order, e->cost,
                                    1, 0, e->snap, e->isnap);
@@ -690,6 +711,7 @@ int rr_rollout(rr_env *e, const int32_t *actions, int32_t na, int32_t nsteps, in
     if (nsteps < 1 || nsteps > 4096) return fail(-1, "rr_rollout: nsteps must be in 1..4096");
     if (e->custom_prog || e->track_prior || e->gs)
         return fail(-1, "rr_rollout: the side kernels of a custom reward program / prior-step tracking / goal scoring bracket single steps; use rr_step");
+    if (e->park) return fail(-1, "rr_rollout: not on a handle that has had a step budget (arenas may be parked mid-step); use rr_step");
     return step_impl<float>(e, actions, nullptr, na, obs, reward, done, obs_g, reward_g, status, stream, (int)nsteps, repeat != 0);
 }
 int rr_step_thrust(rr_env *e, const float *thrust, int32_t nk, float *obs, float *reward, uint8_t *done, float *obs_g,
@@ -701,6 +723,11 @@ int rr_step_f64(rr_env *e, const int32_t *actions, int32_t na, double *obs, doub
                 double *reward_g, int32_t *status, void *stream) {
     if (int rc = check_step_args(e, actions, na, obs, reward, done)) return rc;
     return step_impl<double>(e, actions, nullptr, na, obs, reward, done, obs_g, reward_g, status, stream);
+}
+int rr_step_thrust_f64(rr_env *e, const float *thrust, int32_t nk, double *obs, double *reward, uint8_t *done, double *obs_g,
+                       double *reward_g, int32_t *status, void *stream) {
+    if (int rc = check_step_args(e, thrust, nk, obs, reward, done)) return rc;
+    return step_impl<double>(e, nullptr, thrust, nk, obs, reward, done, obs_g, reward_g, status, stream);
 }
 
 static int ensure_snapshot_buffer(rr_env *e) { // on_step_begin snapshot of every arena (xs_stride reals each)
@@ -717,6 +744,10 @@ int rr_set_reward_program(rr_env *e, const int32_t *ids, int32_t n) {
     for (int i = 0; i < n; i++)
         if (ids[i] < KEEPER_NAUGHTY || ids[i] > KEEPER_PUSHNEG) return fail(-1, "rr_set_reward_program: unknown keeper id");
     DeviceGuard guard(e->cfg.device);
+    {
+        const bool custom = !(n == 3 && ids[0] == KEEPER_NAUGHTY && ids[1] == KEEPER_CHASE && ids[2] == KEEPER_PUSHPOS);
+        if (custom && e->park) return fail(-1, "rr_set_reward_program: a custom program cannot be combined with a step budget");
+    }
     e->prog.n = n;
     for (int i = 0; i < n; i++) e->prog.id[i] = ids[i];
     e->custom_prog = !(n == 3 && ids[0] == KEEPER_NAUGHTY && ids[1] == KEEPER_CHASE && ids[2] == KEEPER_PUSHPOS);
@@ -725,6 +756,25 @@ int rr_set_reward_program(rr_env *e, const int32_t *ids, int32_t n) {
         if (int rc = ensure_snapshot_buffer(e)) return rc;
         if (!e->status_buf) HIP_TRY(hipMalloc((void **)&e->status_buf, sizeof(int32_t) * (size_t)e->cfg.num_envs));
     }
+    return 0;
+}
+
+int rr_set_step_budget(rr_env *e, uint32_t clocks) {
+    if (!e) return fail(-1, "rr_set_step_budget: null handle");
+    if (clocks && (e->custom_prog || e->track_prior || e->gs))
+        return fail(-1, "rr_set_step_budget: SimpleDuel3's own reward stack only (no custom reward program / prior-step tracking / goal scoring)");
+    DeviceGuard guard(e->cfg.device);
+    if (clocks && !e->park) {
+        size_t words = 0;
+        dispatch(e, [&](auto c) { using CC = decltype(c); words = Arena<CC>::PARK_WORDS; return 0; });
+        if (hipMalloc((void **)&e->park, 4 * words * (size_t)e->cfg.num_envs) != hipSuccess) {
+            e->park = nullptr;
+            return fail(-3, "rr_set_step_budget: out of device memory");
+        }
+    }
+    // 0 after a budget: arenas may still be parked mid-step, so the budgeted kernel stays in charge with a budget nothing
+    // exceeds (it resumes them and parks nothing); a handle that never had a budget keeps the default kernel
+    e->budget = clocks ? clocks : 0xFFFFFFFFu;
     return 0;
 }
 

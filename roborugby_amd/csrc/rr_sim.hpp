@@ -137,7 +137,8 @@ enum : int {
     ST_BOT_RESOLVE_FAIL = 1, ST_BOT_STUCK = 2, ST_UNDO_MOVE_FAIL = 4, ST_UNDO_FAIL = 8, ST_SAME_SPOT = 16,
     ST_DIV0 = 32, ST_STEP_AFTER_DONE = 64, ST_BAD_ACTION = 128, ST_UNDO_WARN = 256, ST_RESET_GAVE_UP = 512,
     ST_WAS_RESET = 1024,
-    ST_GOAL_H_DESTROYED = 2048, ST_GOAL_G_DESTROYED = 4096, ST_NO_BALLS = 8192 // opt-in goal scoring (rr_extras.hpp: goal_step)
+    ST_GOAL_H_DESTROYED = 2048, ST_GOAL_G_DESTROYED = 4096, ST_NO_BALLS = 8192, // opt-in goal scoring (rr_extras.hpp: goal_step)
+    ST_NOT_READY = 16384 // budgeted step: the arena's step is still in progress (parked mid-step); its outputs were not written
 };
 
 // ------------------------------------------------------------------------------------------------ math
@@ -399,6 +400,9 @@ template <class C> struct ArenaBody {
     static constexpr int I_STRIDE = P_STRIDE * WR;                         // the same stride seen from the int part (irecs = recs + P_REALS)
     // fixed-point snapshot (its own buffer, touched only by arenas that ran the expensive contact paths): P + ax, ay, arot
     static constexpr int SNAP_WORDS = (P_REALS + 3 * NR) * WR, ISNAP_WORDS = 2 * NR;
+    // parked mid-step state of the budgeted step (its own buffer, touched only by arenas that park): PARK_INTS ints, then
+    // ax, ay, arot, psx, psy [NR each], dist_sum0, exc [NB]
+    static constexpr int PARK_INTS = 10, PARK_REALS = 5 * NR + 1 + NB, PARK_WORDS = PARK_INTS + PARK_REALS * WR;
 };
 // LDS bank spreading.  The 64/VW arenas of a wavefront sit in consecutive LDS slices and their lanes touch the SAME
 // field at the same time, so the slice stride decides the banking: lane-strided accesses of one arena cover
@@ -2171,12 +2175,105 @@ RR_HD int fz_bits_status(uint32_t pk) { return (int)((pk >> 4) & 63u) | (int)(((
 RR_HD float bits_float(int32_t v) { float f; __builtin_memcpy(&f, &v, 4); return f; }
 RR_HD int32_t float_bits(float f) { int32_t v; __builtin_memcpy(&v, &f, 4); return v; }
 
+// Budgeted step (opt-in, rr_config.step_budget_clocks / rr_set_step_budget; BUDGET = false compiles all of it out).
+// A launch ends when its slowest arena does, and under a contact-rich policy one arena in 65,536 needs 10-20x the
+// median step (ten resolve passes + undo in every sub-step) while two thirds of the chip idle behind it.  With a budget, an
+// arena whose step is over the budget at the end of an expensive sub-step PARKS: the few values a sub-step boundary
+// carries besides the persistent record -- sub-step index, surviving-move mask, the step's NaughtyBots / status
+// accumulators, the frozen island, the frame-begin poses (ax, ay, arot), the step-begin copies the rewards read (psx, psy,
+// dist_sum0), how each robot's last move met the walls (wm), the frozen balls' excursions -- go to its slot of a side buffer,
+// bit 31 of the record's `fzp` word marks it, the call reports ST_NOT_READY for it (reward 0, done 0, observation rows NOT
+// written) and the other arenas of its wavefront run on undisturbed.  The next call resumes it at that sub-step boundary and
+// ignores the action it is given; everything else in LDS is either rewritten at the top of every sub-step (frame hooks)
+// or a cache that derive() / the lazy builders reproduce bit for bit.  So each arena's trajectory, as a function of the actions
+// it ACCEPTED, is the synchronous mode's bit for bit (tests/test_budgeted_step.py: emulation parking at arbitrary boundaries,
+// GPU at budgets from 1 clock up).  Whatever rewrites an arena from outside (reset, rr_set_state, rr_set_poses) clears the
+// word, and with it the parked step.
+struct ParkCtx {
+    uint32_t *buf = nullptr;            // this arena's PARK_WORDS slot
+    uint32_t budget = 0;                // shader clocks (s_memtime ticks) a wavefront may run before its expensive arenas park
+    unsigned long long t_begin = 0;     // s_memtime at the wavefront's start
+    uint32_t *host_rng = nullptr;       // host emulation only: park at pseudo-random sub-step boundaries, quiet ones included
+    uint32_t host_mod = 0;              //   (1 in host_mod; <= 1: at every boundary)
+    RR_HD bool over(int work) const {
+#if RR_GPU
+        return work > 0 && (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin) > (unsigned long long)budget;
+#else
+        (void)work;
+        if (!host_rng) return false;
+        *host_rng = *host_rng * 1664525u + 1013904223u;
+        return host_mod <= 1 || ((*host_rng >> 16) % host_mod) == 0;
+#endif
+    }
+};
+constexpr int32_t FZP_PARKED = (int32_t)0x80000000; // Arena::I::fzp while the arena is parked mid-step
+
+template <class C>
+RR_HD void park_save(Arena<C> &A, uint32_t *buf, int f_next, uint32_t prev_moved, uint32_t naughty, int st, const Hit &fz,
+                     uint32_t fz_bits, bool snap_valid, uint32_t snap_moved, typename C::Real dist_sum0) {
+    using R = typename C::Real;
+    constexpr int NR = C::NR, NB = C::NB;
+    int32_t *pi = reinterpret_cast<int32_t *>(buf);
+    R *pr = reinterpret_cast<R *>(buf + Arena<C>::PARK_INTS);
+    RR_FOR_LANES(l) {
+        if (l < NR) { pr[l] = A.ax[l]; pr[NR + l] = A.ay[l]; pr[2 * NR + l] = A.arot[l]; pr[3 * NR + l] = A.psx[l]; pr[4 * NR + l] = A.psy[l]; }
+        if (l < NB) pr[5 * NR + 1 + l] = A.exc[l];
+        if (l == 0) {
+            uint32_t wmb = 0;
+            for (int r = 0; r < NR; r++) wmb |= (uint32_t)(A.wm[r] & 3) << (2 * r);
+            pr[5 * NR] = dist_sum0;
+            pi[0] = f_next; pi[1] = (int32_t)prev_moved; pi[2] = (int32_t)naughty; pi[3] = st; pi[4] = (int32_t)fz.r; pi[5] = (int32_t)fz.b;
+            pi[6] = (int32_t)fz_bits; pi[7] = snap_valid ? 1 : 0; pi[8] = (int32_t)snap_moved; pi[9] = (int32_t)wmb;
+            A.i.fzp = FZP_PARKED;
+        }
+    }
+    RR_SYNC();
+}
+template <class C>
+RR_HD void park_load(Arena<C> &A, const uint32_t *buf, int &f_next, uint32_t &prev_moved, uint32_t &naughty, int &st, Hit &fz,
+                     uint32_t &fz_bits, int &snap_at, uint32_t &snap_moved, typename C::Real &dist_sum0) {
+    using R = typename C::Real;
+    constexpr int NR = C::NR, NB = C::NB;
+    static_assert(NR <= 16, "wm bytes travel as 2 bits per robot in one word");
+    const int32_t *pi = reinterpret_cast<const int32_t *>(buf);
+    const R *pr = reinterpret_cast<const R *>(buf + Arena<C>::PARK_INTS);
+    const uint32_t wmb = (uint32_t)pi[9];
+    RR_FOR_LANES(l) {
+        if (l < NR) {
+            A.ax[l] = pr[l]; A.ay[l] = pr[NR + l]; A.arot[l] = pr[2 * NR + l]; A.psx[l] = pr[3 * NR + l]; A.psy[l] = pr[4 * NR + l];
+            A.wm[l] = (uint8_t)((wmb >> (2 * l)) & 3u);
+        }
+        if (l < NB) A.exc[l] = pr[5 * NR + 1 + l];
+    }
+    dist_sum0 = pr[5 * NR];
+    f_next = pi[0]; prev_moved = (uint32_t)pi[1]; naughty = (uint32_t)pi[2]; st = pi[3]; fz.r = (uint32_t)pi[4]; fz.b = (uint32_t)pi[5];
+    fz_bits = (uint32_t)pi[6]; snap_at = pi[7] ? f_next - 1 : -2; snap_moved = (uint32_t)pi[8];
+    RR_SYNC();
+}
+
 // actions: this arena's na discrete actions (thrust == nullptr) or 2*na thrust floats
-template <class C, typename O>
+template <class C, typename O, bool BUDGET = false>
 RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64_t arena_gid, const int32_t *actions,
-                      const float *thrust, int na, const StepOut<O> &o) {
+                      const float *thrust, int na, const StepOut<O> &o, const ParkCtx &pk = ParkCtx()) {
     using R = typename C::Real;
     int st = 0;
+    R dist_sum0 = (R)0;
+    uint32_t naughty = 0;
+    uint32_t prev_moved = 0, snap_moved = 0;
+    int snap_at = -2; // sub-step whose end state the snapshot holds
+    Hit fz = { 0, 0 }; // the frozen island (see substep)
+    uint32_t fz_bits = 0; // NaughtyBots members + status bits of one computed sub-step of the frozen island (fz_pack_bits)
+    int f0 = 0; // first sub-step to run: 0, or where a parked step goes on
+    constexpr bool FZP = C::NR <= 4 && C::NB <= 8; // what the packed word holds
+    bool resumed = false;
+    if constexpr (BUDGET) {
+        resumed = A.i.fzp < 0; // uniform per arena (read after load_record's sync)
+        if (RR_UNLIKELY(resumed)) {
+            park_load(A, pk.buf, f0, prev_moved, naughty, st, fz, fz_bits, snap_at, snap_moved, dist_sum0);
+            RR_TRACE("E resumed at sub-step %d\n", f0);
+        }
+    }
+    if (!resumed) {
     // raw mode raises when stepping a finished game (:261-262); with auto_reset the call resets instead
     if (RR_UNLIKELY((sp.time_limit ? (A.i.step >= sp.game_len) : (A.i.step > sp.game_len)) || A.i.fault)) {
         if (sp.auto_reset) {
@@ -2220,10 +2317,8 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
         }
     }
     RR_SYNC();
-    R dist_sum0 = (R)0;
     for (int b = 0; b < C::NBP; b++) dist_sum0 = dist_sum0 + A.u.lidar[1][b];
     RR_SYNC();
-    constexpr bool FZP = C::NR <= 4 && C::NB <= 8; // what the packed word holds
     uint64_t m_thr = 0; // robots whose thrust this step changes
     RR_FOR_LANES(l) {
         bool thr_chg = false;
@@ -2249,12 +2344,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     }
     if (!thrust) for (int q = 0; q < na && q < C::NR; q++) { int a = actions[q]; if (a < 0 || a > 7) st |= ST_BAD_ACTION; }
     RR_SYNC();
-    uint32_t naughty = 0;
     RR_STAMP(8);
-    uint32_t prev_moved = 0, snap_moved = 0;
-    int snap_at = -2; // sub-step whose end state the snapshot holds
-    Hit fz = { 0, 0 }; // the frozen island (see substep)
-    uint32_t fz_bits = 0; // NaughtyBots members + status bits of one computed sub-step of the frozen island (fz_pack_bits)
     if (FZP) { // the island the last step ended with, if its robots keep their thrust (see above)
         const uint32_t fzp = o.snap() ? (uint32_t)A.i.fzp : 0u;
         if (RR_UNLIKELY(fzp != 0u) && !((uint32_t)m_thr & fzp & 0xFu)) {
@@ -2269,12 +2359,13 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
             RR_TRACE("E step begins frozen: robots %x balls %x\n", fz.r, fz.b);
         }
     }
+    } // !resumed
 #if defined(RR_PROFILE_PHASES)
     int dbg_work_ = 0;
     const int dbg_frozen_ = (fz.r | fz.b) ? 1 : 0;
 #endif
 #pragma unroll 1
-    for (int f = 0; f < RR_NUM_SUBSTEPS; f++) { // MOVES_PER_FRAME
+    for (int f = f0; f < RR_NUM_SUBSTEPS; f++) { // MOVES_PER_FRAME
         int work = 0;
         Hit hit = { 0, 0 };
         uint32_t n_sub = 0; // what THIS sub-step adds: a freeze keeps it for the frozen sub-steps of later steps
@@ -2320,6 +2411,18 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
             }
             snap_at = f; snap_moved = prev_moved;
         }
+        if constexpr (BUDGET) { // over the budget after an expensive sub-step, and more to come: park at this boundary
+            if (f + 1 < RR_NUM_SUBSTEPS && RR_UNLIKELY(pk.over(work))) {
+                RR_TRACE("E parked after sub-step %d\n", f);
+                park_save(A, pk.buf, f + 1, prev_moved, naughty, st, fz, fz_bits, snap_at == f, snap_moved, dist_sum0);
+                if (RR_IS_LANE0) {
+                    *o.reward() = (O)0; *o.done() = 0;
+                    if (o.reward_g()) *o.reward_g() = (O)0;
+                    if (o.status()) *o.status() = ST_NOT_READY;
+                }
+                return;
+            }
+        }
     }
     if (FZP) { // still frozen: the next step may start that way
         int32_t fzw = 0, fex = 0;
@@ -2332,6 +2435,8 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
             fex = float_bits((float)emax * 1.000001f + 1e-30f); // rounded up: a larger reach only thaws earlier
         }
         if (RR_IS_LANE0) { A.i.fzp = fzw; A.i.fexc = fex; }
+    } else if (BUDGET) {
+        if (RR_IS_LANE0) A.i.fzp = 0; // (configurations without a carried island: the word only ever holds the parked mark)
     }
     substeps_end(A, prev_moved);
     RR_STAMP(9);

@@ -29,18 +29,29 @@ def _backend():
     return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
 
 
+def backend_name():
+    """'nccl' (= RCCL on ROCm), 'gloo', or None without a process group -- what bench.py records next to its collective count."""
+    return _backend()
+
+
 def init_process_group(backend=None):
     """Returns (rank, device_index, world).  The device is selected -- and, for RCCL, bound to the process group
     (device_id: eager communicator, no "guessing device ID" at the first barrier) -- BEFORE the group exists."""
     rank, local_rank, world = dist_env()
     dev = local_device_index(local_rank)
-    if torch.cuda.is_available():
+    # the backend is resolved FIRST: only RCCL needs a device bound per rank.  A gloo group (CPU tests, the one-GPU
+    # rehearsal) binds a device only when that ordinal exists -- two gloo ranks with LOCAL_RANK 0/1 on a one-GPU box must not
+    # die with "invalid device ordinal", and a CPU-only gloo run must not create a GPU context on every rank.
+    backend = backend or os.environ.get("RR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if backend == "nccl":
         torch.cuda.set_device(dev)
+    elif (os.environ.get("RR_SHARE_GPU") or os.environ.get("RR_BENCH_SHARE_GPU")) and torch.cuda.is_available():
+        torch.cuda.set_device(dev)  # the rehearsal: every rank steps its shard on cuda:0
+    # (any other gloo group: no device is touched here; callers address `cuda:<dev>` explicitly if they use the GPU)
     # (RR_DIST_FORCE_INIT=1 builds the group even for a single rank: lets a one-GPU box exercise the RCCL code path itself)
     if (world > 1 or os.environ.get("RR_DIST_FORCE_INIT")) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or os.environ.get("RR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", dev)

@@ -49,8 +49,11 @@ class _WideBatchLinear(torch.autograd.Function):
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         gx = g @ w if ctx.needs_input_grad[0] else None
-        n = x.shape[0] // _WideBatchLinear.SLICE
-        gw = torch.bmm(g.view(n, _WideBatchLinear.SLICE, -1).transpose(1, 2), x.view(n, _WideBatchLinear.SLICE, -1)).sum(0)
+        S = _WideBatchLinear.SLICE
+        if S <= 0 or x.shape[0] % S:  # (_linear only routes whole multiples here; anything else takes the plain GEMM)
+            return gx, g.t() @ x, g.sum(0)
+        n = x.shape[0] // S
+        gw = torch.bmm(g.reshape(n, S, -1).transpose(1, 2), x.reshape(n, S, -1)).sum(0)  # reshape: g may arrive non-contiguous
         return gx, gw, g.sum(0)
 
 
@@ -167,8 +170,9 @@ class BatchedDQNAgent:
     def _try_capture(self, max_mem):
         """Once the replay memory is full the learn step has a fixed shape: capture it into a HIP graph (the step is ~25
         small kernels and launch-bound).  Any failure leaves the eager path in place.  The warm-up iterations PyTorch wants
-        before a capture run with the learning rate at 0 and on a scratch copy of the optimizer state and of the sampling
-        generator, so a graph run makes exactly the updates -- and the random draws -- an eager run makes."""
+        before a capture are REAL Adam steps on a side stream; afterwards the parameters, the optimizer state (moments, step
+        count) and the sampling generator are restored from the copies taken on entry, so a graph run makes exactly the updates
+        -- and the random draws -- an eager run makes."""
         self._graph_tried = True
         opt = self.Q_eval.optimizer
         saved_opt = copy.deepcopy(opt.state_dict())

@@ -30,6 +30,7 @@ STATUS_BITS = {
 }
 STATUS_WARN, STATUS_RESET_GAVE_UP, STATUS_WAS_RESET = 256, 512, 1024
 STATUS_GOAL_H_DESTROYED, STATUS_GOAL_G_DESTROYED, STATUS_NO_BALLS = 2048, 4096, 8192  # opt-in goal scoring only
+STATUS_NOT_READY = 16384  # budgeted step only (step_budget_clocks > 0): the arena's step is still in progress
 STATUS_FLAG_MASK, STATUS_NAUGHTY_SHIFT = 0xFFFF, 16  # info.status: flags in bits 0-15, NaughtyBots' robots in bits 16+
 
 # reward mixins of RR_ScoreKeepers.py (ids of the C-ABI's keeper program) and observer mixins of RR_Observers.py
@@ -88,6 +89,12 @@ class BatchedRoboRugbyEnv:
     instead of raising "Game is over" -- the policy's action for that arena is ignored on that call.  With
     reset_on_fault (default = auto_reset) a step in which the reference would have raised or hung
     (info.status bits 1|2|4|8|16|32) also reports done=True, so faulted arenas are re-placed instead of lingering.
+
+    step_budget_clocks > 0 selects the BUDGETED step (opt-in extension, include/roborugby_amd.h): a call no longer waits for its
+    slowest arena -- an arena whose wavefront is over the budget (shader clocks) at the end of an expensive physics sub-step
+    parks there, the call reports STATUS_NOT_READY for it (reward 0, done False, its observation row keeps the previous
+    values: step() then hands out persistent buffers) and the next call resumes it, ignoring the action it is given.  Each
+    arena's trajectory as a function of the actions it accepted is bit-identical to the synchronous mode.
     """
     metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 30}
     reward_range = (-float("inf"), float("inf"))
@@ -95,7 +102,7 @@ class BatchedRoboRugbyEnv:
     def __init__(self, num_envs, preset="T", device=None, seed=0, time_limit=True, auto_reset=True, dtype="f64",
                  arena_offset=0, env_id="RoboRugbySimpleDuel-v3", reset_on_fault=None, action_mode="discrete",
                  rewards=SIMPLE_DUEL3_REWARDS, observer="SingleBall_6wayLidar_v2", lst_starting_config=None,
-                 goal_scoring=False):
+                 goal_scoring=False, step_budget_clocks=0):
         self.preset = PRESETS[preset] if isinstance(preset, str) else preset
         assert isinstance(self.preset, Preset)
         if not torch.cuda.is_available():
@@ -118,7 +125,9 @@ class BatchedRoboRugbyEnv:
             game_mode=int(p.game_mode), time_limit=int(self.time_limit), auto_reset=int(self.auto_reset),
             reset_on_fault=int(self.reset_on_fault),
             dtype={"f64": 0, "f32": 1}[dtype], device=self.device.index or 0, seed=int(seed),
-            arena_offset=int(arena_offset))
+            arena_offset=int(arena_offset), step_budget_clocks=int(step_budget_clocks), reserved_=0)
+        self.step_budget_clocks = int(step_budget_clocks)
+        self._bout = None  # persistent step outputs of the budgeted mode (NOT_READY rows keep their previous observation)
         h = C.c_void_p()
         _lib.check(self._lib.rr_create(C.byref(cfg), C.byref(h)), "rr_create")
         self._h = h
@@ -190,20 +199,34 @@ class BatchedRoboRugbyEnv:
         _lib.check(self._lib.rr_reset_to_poses(self._h, _ptr(mask), _ptr(self._start_robots), _ptr(self._start_balls), _ptr(obs),
                                                None, self._stream()), "rr_reset_to_poses")
 
-    def reset(self, mask=None, bln_randomize_pos=True):
+    def _mask(self, mask):
+        """uint8 [N] device mask; scalars / wrong sizes are rejected (the kernels index mask[arena] for every arena)."""
+        if mask is None:
+            return None
+        if isinstance(mask, (bool, int, float)) or (hasattr(mask, "ndim") and mask.ndim == 0):
+            raise TypeError("reset(mask=...): a per-arena mask of num_envs booleans is required, not a scalar "
+                            "(the reference's reset(False) is reset(bln_randomize_pos=False) here)")
+        m = torch.as_tensor(mask).to(device=self.device, dtype=torch.uint8).contiguous().view(-1)
+        if m.numel() != self.num_envs:
+            raise ValueError(f"reset(mask=...): {m.numel()} entries for {self.num_envs} arenas")
+        return m
+
+    def reset(self, mask=None, *, bln_randomize_pos=True):
         """env.reset(bln_randomize_pos) (RR_EnvBase.py:202-216) for all arenas, or those where mask is True: a fresh random
         placement (_set_random_positions), or with bln_randomize_pos=False the start configuration kept since construction
         (_set_starting_positions, RR_EnvBase.py:131-153; main.py:107 replays its layout that way)."""
         N = self.num_envs
         obs = self._new((N, 11), torch.float32)
+        mask = self._mask(mask)
         if mask is not None:
-            mask = torch.as_tensor(mask).to(device=self.device, dtype=torch.uint8).contiguous()
             # rows that are not reset keep their current observation
             _lib.check(self._lib.rr_observe(self._h, 1, -1, -1, _ptr(obs), self._stream()), "rr_observe")
         if bln_randomize_pos:
             _lib.check(self._lib.rr_reset(self._h, _ptr(mask), _ptr(obs), None, self._stream()), "rr_reset")
         else:
             self._reset_to_start(mask, obs)
+        if self._bout is not None:  # budgeted mode: a row that is NOT_READY in the next step must find this observation
+            self._bout[0].copy_(obs)
         return obs if self.obs_kind == 0 else self.get_game_state(1)
 
     def starting_positions(self):
@@ -226,6 +249,13 @@ class BatchedRoboRugbyEnv:
         if a.shape[1] > self.preset.nr:  # RR_EnvBase.py:621-622
             raise Exception(f"{a.shape[1]} commands but only {self.preset.nr} robots.")
         a = a.to(torch.int32).contiguous()
+        own = out is None and bool(self.step_budget_clocks)
+        if own:
+            if self._bout is None:  # rows of parked arenas are not written: they must find their previous observation here
+                self._bout = (torch.zeros(N, 11, device=self.device), self._new((N,), torch.float32), self._new((N,), torch.uint8),
+                              torch.zeros(N, 11, device=self.device) if self.has_grumpy else None, self._new((N,), torch.float32),
+                              self._new((N,), torch.int32))
+            out = self._bout
         if out is None:
             obs, rew = self._new((N, 11), torch.float32), self._new((N,), torch.float32)
             done = self._new((N,), torch.uint8)
@@ -236,9 +266,17 @@ class BatchedRoboRugbyEnv:
             obs, rew, done, obs_g, rew_g, status = out
         _lib.check(self._lib.rr_step(self._h, _ptr(a), a.shape[1], _ptr(obs), _ptr(rew), _ptr(done), _ptr(obs_g),
                                      _ptr(rew_g), _ptr(status), self._stream()), "rr_step")
+        if own:  # hand out copies: the persistent buffers are overwritten by the next call
+            obs, rew, done, rew_g, status = obs.clone(), rew.clone(), done.clone(), rew_g.clone(), status.clone()
+            obs_g = obs_g.clone() if obs_g is not None else None
         if self.obs_kind != 0:
             obs, obs_g = self.get_game_state(1), (self.get_game_state(-1) if self.has_grumpy else None)
         return obs, rew, done.view(torch.bool), DebugInfo(obs_g, rew_g, status)
+
+    def set_step_budget(self, clocks):
+        """rr_set_step_budget: switch the budgeted step on (clocks > 0) or off (0: parked arenas finish in the next calls)."""
+        _lib.check(self._lib.rr_set_step_budget(self._h, int(clocks)), "rr_set_step_budget")
+        self.step_budget_clocks = int(clocks)
 
     def rollout(self, actions, repeat=None, out=None):
         """Open-loop rollout in ONE launch: `actions` int [S, N] / [S, N, NA] steps the batch S times (or, with
@@ -268,18 +306,21 @@ class BatchedRoboRugbyEnv:
                                         _ptr(status), self._stream()), "rr_rollout")
         return obs, rew, done.view(torch.bool), DebugInfo(obs_g, rew_g, status)
 
-    def step_thrust(self, thrust):
-        """GameEnv.step with continuous (L,R) thrust pairs (RR_EnvBase.py:260-273): float tensor [N, 2*k]."""
+    def step_thrust(self, thrust, f64=False):
+        """GameEnv.step with continuous (L,R) thrust pairs (RR_EnvBase.py:260-273): float tensor [N, 2*k].  f64=True returns the
+        observation / reward in fp64 (rr_step_thrust_f64: the entry's parity checks)."""
         N = self.num_envs
         t = torch.as_tensor(thrust, device=self.device, dtype=torch.float32).contiguous().view(N, -1)
         if t.shape[1] % 2 or t.shape[1] > 2 * self.preset.nr:  # RR_EnvBase.py:270-271
             raise Exception(f"{t.shape[1]} commands but only {self.preset.nr * 2} robot engines.")
-        obs, rew = self._new((N, 11), torch.float32), self._new((N,), torch.float32)
+        od = torch.float64 if f64 else torch.float32
+        obs, rew = self._new((N, 11), od), self._new((N,), od)
         done = self._new((N,), torch.uint8)
-        obs_g = self._new((N, 11), torch.float32) if self.has_grumpy else None
-        rew_g, status = self._new((N,), torch.float32), self._new((N,), torch.int32)
-        _lib.check(self._lib.rr_step_thrust(self._h, _ptr(t), t.shape[1] // 2, _ptr(obs), _ptr(rew), _ptr(done),
-                                            _ptr(obs_g), _ptr(rew_g), _ptr(status), self._stream()), "rr_step_thrust")
+        obs_g = self._new((N, 11), od) if self.has_grumpy else None
+        rew_g, status = self._new((N,), od), self._new((N,), torch.int32)
+        fn = self._lib.rr_step_thrust_f64 if f64 else self._lib.rr_step_thrust
+        _lib.check(fn(self._h, _ptr(t), t.shape[1] // 2, _ptr(obs), _ptr(rew), _ptr(done),
+                      _ptr(obs_g), _ptr(rew_g), _ptr(status), self._stream()), "rr_step_thrust")
         if self.obs_kind != 0:
             obs, obs_g = self.get_game_state(1), (self.get_game_state(-1) if self.has_grumpy else None)
         return obs, rew, done.view(torch.bool), DebugInfo(obs_g, rew_g, status)

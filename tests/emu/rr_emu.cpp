@@ -5,6 +5,8 @@
 static int g_dbg_substeps = 12;
 static int g_dbg_trace = 0;
 static int g_dbg_memo = 1; // fixed-point check of the sub-step loop on/off (tests compare both)
+static int g_dbg_scrub = 0; // overwrite everything but the persistent record with garbage before each step, then derive(): what a
+                            // GPU launch starts from (load_record + derive into an LDS slice that holds another arena's leftovers)
 #define RR_NUM_SUBSTEPS g_dbg_substeps
 #define RR_EMU_TRACE g_dbg_trace
 #include "../../roborugby_amd/csrc/rr_sim.hpp"
@@ -25,6 +27,8 @@ template <class C> struct Emu {
     int32_t isnap[2 * C::NR];
     int goal_scoring;              // opt-in goal scoring (rr_extras.hpp: goal_step)
     int32_t gs[1 + 2 * C::NB + 4];
+    uint32_t park[Arena<C>::PARK_WORDS]; // budgeted step: the parked mid-step state (what the GPU keeps in its side buffer)
+    uint32_t park_rng;
 };
 
 template <typename R> static void fill_params(SimParams<R> &sp, double W, double H, int game_len, int game_mode,
@@ -104,6 +108,7 @@ void emu_goal_scores(Handle *h, int32_t *s2) {
 }
 void emu_debug_trace(int on) { g_dbg_trace = on; }
 void emu_debug_memo(int on) { g_dbg_memo = on; }
+void emu_debug_scrub(int on) { g_dbg_scrub = on; }
 // primitives of the kernel source, for unit tests
 double emu_py_mod360(double a) { return py_mod<double>(a, 360.0); }
 void emu_sincos(double x, double *s, double *c) { m_sincos(x, *s, *c); }
@@ -145,14 +150,31 @@ void emu_set_poses(Handle *h, const double *rxyr, const double *bxyv) {
 }
 // same bracketing as rr_step: snapshot -> step kernel phases -> keeper program (only for a non-default program)
 extern "C++" {
+template <class CC> static void scrub_scratch(Emu<CC> *e) {
+    // keep P and I (the HBM record), trash the rest of the LDS image, rebuild what the kernel derives after load_record
+    typename Arena<CC>::P p = e->A.p;
+    typename Arena<CC>::I i = e->A.i;
+    memset(&e->A, 0xA5, sizeof(e->A));
+    e->A.p = p; e->A.i = i;
+    derive(e->A, e->sp);
+}
+// park_mod < 0: the synchronous step; >= 0: the budgeted step, parking at pseudo-random sub-step boundaries (1 in park_mod; 0 / 1: all)
 template <class CC> static int emu_step_t(Emu<CC> *e, const int32_t *actions, const float *thrust, int na, double *obs,
-                                          double *obs_g, double *reward, double *reward_g, uint8_t *done) {
+                                          double *obs_g, double *reward, double *reward_g, uint8_t *done, int park_mod = -1) {
     using RR = typename CC::Real;
     int32_t status = 0;
     RR *xs = e->xs;
     Rec<CC> q = { reinterpret_cast<const RR *>(&e->A.p) };
-    extras_begin<CC>(q, xs);
+    if (g_dbg_scrub) scrub_scratch(e);
+    const bool was_parked = e->A.i.fzp < 0;
+    if (!was_parked) extras_begin<CC>(q, xs);
     StepOut<double> o = { obs, obs_g, reward, reward_g, done, &status, g_dbg_memo ? e->snap : nullptr, e->isnap, 0, 0, 0 };
+    if (park_mod >= 0) {
+        ParkCtx pk;
+        pk.buf = e->park; pk.host_rng = &e->park_rng; pk.host_mod = (uint32_t)park_mod;
+        step_arena<CC, double, true>(e->A, e->sp, 0, actions, thrust, na, o, pk);
+        if (status & ST_NOT_READY) return status;
+    } else
     step_arena<CC, double>(e->A, e->sp, 0, actions, thrust, na, o);
     if (e->custom_prog && !(status & (ST_WAS_RESET | ST_STEP_AFTER_DONE))) {
         RR rh, rg;
@@ -172,6 +194,14 @@ int emu_step(Handle *h, const int32_t *actions, int na, double *obs, double *obs
     DISPATCH(h, status = emu_step_t<CC>(e, actions, nullptr, na, obs, obs_g, reward, reward_g, done));
     return status;
 }
+// the budgeted step (rr_sim.hpp: ParkCtx): returns ST_NOT_READY while the step is parked; outputs are written when it completes
+int emu_step_budget(Handle *h, const int32_t *actions, int na, double *obs, double *obs_g, double *reward, double *reward_g,
+                    uint8_t *done, int park_mod) {
+    int32_t status = 0;
+    DISPATCH(h, status = emu_step_t<CC>(e, actions, nullptr, na, obs, obs_g, reward, reward_g, done, park_mod < 0 ? 0 : park_mod));
+    return status;
+}
+void emu_park_seed(Handle *h, uint32_t seed) { DISPATCH(h, e->park_rng = seed); }
 int emu_step_thrust(Handle *h, const float *thrust, int nk, double *obs, double *obs_g, double *reward, double *reward_g,
                     uint8_t *done) {
     int32_t status = 0;

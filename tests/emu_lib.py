@@ -36,6 +36,8 @@ def lib():
         L.emu_get_state.argtypes = [C.c_void_p, dp, ip, dp, ip]
         L.emu_set_poses.argtypes = [C.c_void_p, dp, dp]
         L.emu_step.argtypes = [C.c_void_p, ip, C.c_int, dp, dp, dp, dp, u8p]
+        L.emu_step_budget.argtypes = [C.c_void_p, ip, C.c_int, dp, dp, dp, dp, u8p, C.c_int]
+        L.emu_park_seed.argtypes = [C.c_void_p, C.c_uint32]
         L.emu_step_thrust.argtypes = [C.c_void_p, fp, C.c_int, dp, dp, dp, dp, u8p]
         L.emu_observe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, dp]
         L.emu_reset.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
@@ -101,6 +103,22 @@ class EmuEnv:
         # status word: flags in bits 0-15, NaughtyBots' robot set in bits 16+
         return dict(obs=obs, obs_g=obs_g, reward=float(rew[0]), reward_g=float(rew_g[0]), done=bool(done[0]),
                     status=int(st) & 0xFFFF, naughty=(int(st) >> 16) & 0xFF)
+
+    def step_budget(self, actions, park_mod=3):
+        """The budgeted step of the kernel source (rr_sim.hpp: ParkCtx): parks at pseudo-random sub-step boundaries (1 in park_mod).
+        Returns None while the step is parked (status NOT_READY: nothing was written), else the usual dict."""
+        a = np.ascontiguousarray(np.asarray(actions).reshape(-1), np.int32)
+        obs, obs_g, rew, rew_g = np.zeros(11), np.zeros(11), np.zeros(1), np.zeros(1)
+        done = np.zeros(1, np.uint8)
+        st = lib().emu_step_budget(self.h, _ip(a), len(a), _dp(obs), _dp(obs_g), _dp(rew), _dp(rew_g),
+                                   done.ctypes.data_as(C.POINTER(C.c_uint8)), int(park_mod))
+        if int(st) & 16384:
+            return None
+        return dict(obs=obs, obs_g=obs_g, reward=float(rew[0]), reward_g=float(rew_g[0]), done=bool(done[0]),
+                    status=int(st) & 0xFFFF, naughty=(int(st) >> 16) & 0xFF)
+
+    def park_seed(self, seed):
+        lib().emu_park_seed(self.h, int(seed) & 0xFFFFFFFF)
 
     def set_program(self, ids):
         a = np.ascontiguousarray(ids, np.int32)

@@ -29,13 +29,13 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/roborugby_amd.h but not exported"
     assert set(decl) == set(_lib.SYMBOLS), (set(decl) ^ set(_lib.SYMBOLS))
     lib.rr_abi_version.restype = C.c_int
-    assert lib.rr_abi_version() == 3
+    assert lib.rr_abi_version() == 4
 
 
 def test_config_struct_matches_header_layout():
     from roborugby_amd import _lib
-    # 2+4 int32, 2 double, 7 int32 (+4 pad), 2 uint64 with natural alignment = 88 bytes
-    assert C.sizeof(_lib.RRConfig) == 88
+    # 2+4 int32, 2 double, 7 int32 (+4 pad), 2 uint64, 2 uint32 with natural alignment = 96 bytes
+    assert C.sizeof(_lib.RRConfig) == 96 and _lib.RRConfig.step_budget_clocks.offset == 88
     assert _lib.RRConfig.arena_w.offset == 24 and _lib.RRConfig.reset_on_fault.offset == 56
     assert _lib.RRConfig.seed.offset == 72
 

@@ -1,0 +1,143 @@
+"""The budgeted step on the MI355X, through the C-ABI (rr_config.step_budget_clocks / rr_set_step_budget; rr_sim.hpp: ParkCtx).
+
+Promise: each arena's stream of (observation, reward, done, status), as a function of the actions it ACCEPTED, is the
+synchronous mode's bit for bit -- whatever the budget, down to 1 clock (every expensive sub-step parks).  Checked on the stuck
+arenas taken from the slowest wavefronts of chase-policy rollouts (tests/data/stuck_chase_*.npz) and on a 65,536-arena
+chase-policy rollout with the policy in the loop.  tests/test_budgeted_step.py is the CPU twin (host-emulated wave)."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+NOT_READY = 16384
+
+
+def _chase(obs, cursor, table):
+    """turn toward the ball, else forward; the noise of an arena's k-th accepted step comes from table[k, arena]: the action is a
+    function of the arena's own observation and of how many steps it has accepted -- the same in both modes."""
+    n = obs.shape[0]
+    d = (obs[:, 1] - obs[:, 0] + 540.0) % 360.0 - 180.0
+    a = torch.where(d.abs() < 8, 0, torch.where(d > 0, 2, 3)).to(torch.int32)
+    row = table[cursor.clamp(max=table.shape[0] - 1), torch.arange(n, device=obs.device)]  # [n, na]: >= 8 keeps the chase action
+    a1 = torch.where(row[:, 0] < 8, row[:, 0], a)
+    return torch.cat([a1.view(n, 1), row[:, 1:] % 8], 1).contiguous()
+
+
+def _streams(env, table, steps, budget_mode, max_calls):
+    """runs until every arena has accepted `steps` steps; returns per-arena streams [steps, n, ...] of obs / reward / done / status"""
+    n, dev = env.num_envs, env.device
+    na = table.shape[2]
+    rec_o = torch.zeros(steps, n, 11, device=dev); rec_r = torch.zeros(steps, n, device=dev)
+    rec_d = torch.zeros(steps, n, dtype=torch.uint8, device=dev); rec_s = torch.zeros(steps, n, dtype=torch.int32, device=dev)
+    rec_og = torch.zeros(steps, n, 11, device=dev) if env.has_grumpy else None
+    out = (torch.zeros(n, 11, device=dev), torch.zeros(n, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev),
+           torch.zeros(n, 11, device=dev) if env.has_grumpy else None, torch.zeros(n, device=dev), torch.zeros(n, dtype=torch.int32, device=dev))
+    out[0].copy_(env.get_game_state(1))
+    cursor = torch.zeros(n, dtype=torch.long, device=dev)   # steps accepted AND completed
+    parked = torch.zeros(n, dtype=torch.bool, device=dev)
+    ar = torch.arange(n, device=dev)
+    calls = not_ready_rows = 0
+    while int(cursor.min()) < steps:
+        a = _chase(out[0], cursor, table)
+        if budget_mode:  # a parked arena must ignore what it is given: hand it something else
+            a = torch.where(parked.view(n, 1), (a + 3) % 8, a)
+        env.step(a[:, :na], out=out)
+        calls += 1
+        assert calls <= max_calls, "arenas do not make progress"
+        ready = (out[5] & NOT_READY) == 0
+        assert budget_mode or bool(ready.all())
+        not_ready_rows += int((~ready).sum())
+        idx = ar[ready & (cursor < steps)]
+        c = cursor[idx]
+        rec_o[c, idx] = out[0][idx]; rec_r[c, idx] = out[1][idx]; rec_d[c, idx] = out[2][idx]; rec_s[c, idx] = out[5][idx]
+        if rec_og is not None:
+            rec_og[c, idx] = out[3][idx]
+        cursor += ready.long()
+        parked = ~ready
+    return (rec_o, rec_r, rec_d, rec_s, rec_og), calls, not_ready_rows
+
+
+def _equal(a, b):
+    return all(x is None or torch.equal(torch.nan_to_num(x.float(), nan=-7.0), torch.nan_to_num(y.float(), nan=-7.0)) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("preset", ["T", "G"])
+def test_budgeted_equals_synchronous_on_stuck_chase_arenas(preset):
+    import roborugby_amd as rr
+    d = np.load(os.path.join(HERE, "data", f"stuck_chase_{preset}.npz"))
+    n, na = len(d["step"]), d["actions"].shape[1]
+    steps = 10
+    g = torch.Generator(device="cuda").manual_seed(5)
+    # mostly "keep the fixture's action" (>= 8 -> chase action; here replaced below), sometimes a random one
+    table = torch.randint(0, 8, (steps, n, na), generator=g, device="cuda", dtype=torch.int32)
+    keep = torch.rand(steps, n, generator=g, device="cuda") < 0.7
+    table = torch.where(keep.unsqueeze(-1), torch.as_tensor(d["actions"], device="cuda").to(torch.int32).expand(steps, n, na), table)
+    ref = None
+    for budget in (0, 1, 50_000, 400_000):
+        env = rr.BatchedRoboRugbyEnv(n, preset=preset, seed=3, time_limit=True, auto_reset=True, step_budget_clocks=budget)
+        env.set_state(d["robots"], d["robots_i"], d["balls"], d["step"])
+        got, calls, nr = _streams(env, table, steps, budget > 0, 400)
+        env.close()
+        if ref is None:
+            ref = got
+            assert calls == steps and nr == 0
+        else:
+            assert _equal(got, ref), (preset, budget)
+            if budget == 1:
+                assert nr > n  # these arenas are the stuck ones: with a 1-clock budget they park over and over
+        print(f"[{preset}] budget {budget}: {calls} calls for {steps} steps of {n} stuck arenas, {nr} NOT_READY rows")
+
+
+@pytest.mark.parametrize("preset", ["T", "G"])
+@pytest.mark.timeout(900)
+def test_budgeted_equals_synchronous_on_a_65536_arena_chase_rollout(preset):
+    """the contact-rich regime at full size, policy in the loop: 150 synchronous chase steps bring both envs to the same
+    contact-rich state, then 30 accepted steps per arena are compared between the synchronous mode and two budgets."""
+    import roborugby_amd as rr
+    n, warm, steps = 65536, 150, 30
+    na = 1 if preset == "T" else 4
+    g = torch.Generator(device="cuda").manual_seed(9)
+    table = torch.randint(0, 80, (warm + steps, n, na), generator=g, device="cuda", dtype=torch.int32)  # 10 % random, else chase
+    if na > 1:
+        table[:, :, 1:] %= 8
+    ref = None
+    for budget in (0, 150_000, 600_000):
+        env = rr.BatchedRoboRugbyEnv(n, preset=preset, seed=12, time_limit=True, auto_reset=True)
+        env.reset()
+        _streams(env, table[:warm], warm, False, warm)          # synchronous warm-up: identical in every run
+        env.set_step_budget(budget)
+        got, calls, nr = _streams(env, table[warm:], steps, budget > 0, 40 * steps)
+        if ref is None:
+            ref = got
+        else:
+            assert _equal(got, ref), (preset, budget)
+            assert nr > 0, "no arena ever parked: the budget is not exercised"
+            # switching the budget off lets the parked arenas finish; nothing parks any more
+            env.set_step_budget(0)
+            a = torch.zeros(n, na, dtype=torch.int32, device="cuda")
+            for _ in range(3):
+                o, r, dn, info = env.step(a)
+            assert int((info.status & NOT_READY).sum()) == 0
+        print(f"[{preset}] budget {budget}: {calls} calls until every arena had accepted {steps} steps, {nr} NOT_READY rows "
+              f"({100.0 * nr / (calls * n):.2f} % of the rows)")
+        env.close()
+
+
+def test_budget_rejects_what_it_cannot_bracket():
+    import roborugby_amd as rr
+    from roborugby_amd import _lib
+    env = rr.BatchedRoboRugbyEnv(64, preset="G", step_budget_clocks=1000)
+    a = torch.zeros(5, 64, 4, dtype=torch.int32, device="cuda")
+    with pytest.raises(_lib.RRError, match="step budget"):
+        env.rollout(a)
+    with pytest.raises(_lib.RRError, match="step budget"):
+        prog = np.asarray([1, 2, 3, 4], np.int32)
+        _lib.check(env._lib.rr_set_reward_program(env._h, prog.ctypes.data_as(__import__("ctypes").c_void_p), 4), "rr_set_reward_program")
+    env.close()
+    env = rr.BatchedRoboRugbyEnv(64, preset="G", rewards=("DontDriveInGoals", "PushPosBallsToGoal", "ChasePosBall", "NaughtyBots"))
+    with pytest.raises(_lib.RRError, match="reward stack"):
+        env.set_step_budget(1000)
+    env.close()

@@ -58,24 +58,36 @@ def test_two_processes_on_one_gpu_equal_one_batch(tmp_path):
 
 @pytest.mark.timeout(900)
 def test_bench_gpus_2_prints_a_well_formed_line():
-    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one rank per 'GPU'), both ranks sharing
-    cuda:0 with gloo standing in for RCCL."""
+    """bench.py --gpus 2 with the driver's EXACT flags (torch.distributed.run, one rank per 'GPU', --steps 20 --warmup 5, default
+    arenas and log interval), both ranks sharing cuda:0 with gloo standing in for RCCL: the episode-return all-gather -- the one
+    collective north_star names -- must be issued inside that run (with the interval of 25 it never fired)."""
     port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5",
-           "--arenas", "16384", "--log-interval", "10"]
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"]
     p = subprocess.run(cmd, env=_child_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=840, cwd=REPO)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]  # rank 0 only
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["steps"] == 30 and line["warmup"] == 5 and line["scaling"] == "weak"
+    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["warmup"] == 5 and line["scaling"] == "weak"
     assert line["metric"] == "env_steps_per_sec" and line["unit"] == "env-steps/s" and line["higher_is_better"] is True
     # whole-job value = both shards' steps / max-over-ranks time
-    assert abs(line["value"] - 2 * 16384 * 30 / (line["ms_per_step"] * 30e-3)) / line["value"] < 0.02
-    assert line["config"]["arenas_per_gpu"] == 16384 and "dp2" in line["config"]["sharding"]
+    assert abs(line["value"] - 2 * 65536 * 20 / (line["ms_per_step"] * 20e-3)) / line["value"] < 0.02
+    assert line["config"]["arenas_per_gpu"] == 65536 and "dp2" in line["config"]["sharding"]
+    co = line["config"]["collectives"]
+    assert co["all_gather_calls"] >= 2 and co["ranks"] == 2 and co["backend"] == "gloo" and co["bytes_per_rank"] == 4 * 65536
+    assert co["gathered_rows"] == 2 * 65536  # every rank's returns arrived, in global arena order
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
     assert "cpu_baseline" not in line  # rank 0 at N = 1 only
+
+
+@pytest.mark.timeout(300)
+def test_gloo_ranks_with_a_gpu_visible_do_not_bind_missing_devices():
+    """dist.init_process_group used to call torch.cuda.set_device(LOCAL_RANK) for every backend, so the CPU gloo test
+    (LOCAL_RANK 0 / 1, no RR_SHARE_GPU) died with 'invalid device ordinal' on a one-GPU box.  The same test, with the GPU visible."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import test_dist_gloo
+    test_dist_gloo.test_two_rank_shards_equal_one_big_batch()
 
 
 @pytest.mark.timeout(900)

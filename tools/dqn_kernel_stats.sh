@@ -2,6 +2,7 @@
 # per-kernel GPU time of the batched DQN loop (config 5): rocprofv3 --kernel-trace --stats over a short run
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/dqn_stats; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export PYTHONPATH=$ROOT${PYTHONPATH:+:$PYTHONPATH}  # cwd is /tmp: the package is found through the path, python3 stays right behind `--`
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 -m roborugby_amd.dqn --num-envs 65536 --steps 120 --log-every 0 > $OUT/run.txt 2>&1
 cd $ROOT
 python3 - <<PY

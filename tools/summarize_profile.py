@@ -23,10 +23,21 @@ for kind in ("fetch", "write"):
     rows = [r for r in csv.DictReader(open(f)) if "k_step" in r["Kernel_Name"]]
     vals = [float(r["Counter_Value"]) for r in rows]
     out[rows[0]["Counter_Name"]] = dict(per_launch_values_KB=vals, mean_KB=sum(vals) / len(vals))
-    out["kernel_resources"] = dict(VGPR=int(rows[0]["VGPR_Count"]), AGPR=int(rows[0]["Accum_VGPR_Count"]),
-                                   SGPR=int(rows[0]["SGPR_Count"]), LDS_block=int(rows[0]["LDS_Block_Size"]),
-                                   scratch=int(rows[0]["Scratch_Size"]), workgroup=int(rows[0]["Workgroup_Size"]),
-                                   grid=int(rows[0]["Grid_Size"]))
+    # (rocprofv3's dispatch record: its VGPR_Count is NOT the compiler's register count -- 124 for a kernel the compiler
+    # allocates 246 VGPRs for; the compiler's own remark is attached below as `compiler_resources`)
+    out["rocprofv3_dispatch_fields"] = dict(VGPR_Count=int(rows[0]["VGPR_Count"]), Accum_VGPR_Count=int(rows[0]["Accum_VGPR_Count"]),
+                                            SGPR_Count=int(rows[0]["SGPR_Count"]), LDS_Block_Size=int(rows[0]["LDS_Block_Size"]),
+                                            Scratch_Size=int(rows[0]["Scratch_Size"]), Workgroup_Size=int(rows[0]["Workgroup_Size"]),
+                                            Grid_Size=int(rows[0]["Grid_Size"]))
+kres = f"{out_dir}/kernel_resources.txt"  # `python tools/kernel_resources.py k_step > profiles/<round>/kernel_resources.txt` (no GPU needed)
+if os.path.exists(kres):
+    preset, dtype = key.split("_")[0], key.split("_")[1]
+    shape = "1+0/1+0" if preset == "T" else "2+2/4+4"
+    vw = "VW2" if preset == "T" else "VW8"
+    real = "double" if dtype == "f64" else "float"
+    rows_k = [ln.strip() for ln in open(kres) if shape in ln and f" {real} {vw} " in ln]
+    out["compiler_resources"] = dict(source="hipcc -Rpass-analysis=kernel-resource-usage (tools/kernel_resources.py), same sources",
+                                     k_step_instantiations=rows_k)
 f_, w_ = out["FETCH_SIZE"]["mean_KB"] * 1024, out["WRITE_SIZE"]["mean_KB"] * 1024
 out["hbm_bytes_per_launch"] = dict(
     fetch_raw=f_, fetch_corrected_x2=2 * f_, write=w_, total=2 * f_ + w_,
@@ -36,6 +47,7 @@ out["hbm_bytes_per_env_step"] = (2 * f_ + w_) / n_env
 json.dump(out, open(f"{out_dir}/{key}_summary.json", "w"), indent=1)
 tf = "profiles/traffic.json"
 t = json.load(open(tf)) if os.path.exists(tf) else {}
-t[key] = 2 * f_ + w_
+t[key] = {"bytes": 2 * f_ + w_, "source": f"{out_dir}/{key}_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, "
+                                            f"tools/profile_r01.sh {tag})"}
 json.dump(t, open(tf, "w"), indent=1)
-print(json.dumps({k: out[k] for k in ("avg_ns", "hbm_bytes_per_env_step", "kernel_resources")}))
+print(json.dumps({k: out[k] for k in ("avg_ns", "hbm_bytes_per_env_step")}))
