@@ -113,16 +113,6 @@ def hbm_copy_probe(dev, mib=1024, iters=20):
     return 2.0 * n * 4 / (ms * 1e-3) / 1e9
 
 
-def chase_actions(obs, noise, gen):
-    """turn toward ball_angle, else forward; `noise` fraction random (SURVEY section 8d contact-rich stream)."""
-    import torch
-    d = (obs[:, 1] - obs[:, 0] + 540.0) % 360.0 - 180.0
-    a = torch.where(d.abs() < 8, 0, torch.where(d > 0, 2, 3)).to(torch.int32)
-    r = torch.randint(0, 8, a.shape, generator=gen, device=a.device, dtype=torch.int32)
-    m = torch.rand(a.shape, generator=gen, device=a.device) < noise
-    return torch.where(m, r, a)
-
-
 def pipelined(args):
     """--pipeline P: the same 65,536 arenas, the same K steps each, as P shard envs on P streams (roborugby_amd.ShardedPipeline).
     A shard's step s+1 only waits for its own step s (and its own policy call), so while one shard's launch drains -- a launch
@@ -135,7 +125,8 @@ def pipelined(args):
     torch.cuda.set_device(dev)
     P, N, K, W = args.pipeline, args.arenas, args.steps, args.warmup
     n = N // P
-    pipe = rr.ShardedPipeline(N, shards=P, device=dev, preset=args.preset, seed=0, time_limit=True, auto_reset=True, dtype=args.dtype)
+    pipe = rr.ShardedPipeline(N, shards=P, device=dev, preset=args.preset, seed=0, time_limit=True, auto_reset=True, dtype=args.dtype,
+                              step_budget_clocks=args.budget)
     p = pipe.preset
     na = p.nr
     gens = [torch.Generator(device=dev) for _ in range(P)]
@@ -152,22 +143,29 @@ def pipelined(args):
         step_no[i] += 1
         if acts is not None:
             return acts[s, i * n:(i + 1) * n]
-        a1 = chase_actions(obs, 0.1, gens[i]).view(n, 1)
-        return torch.cat([a1, torch.randint(0, 8, (n, na - 1), generator=gens[i], device=dev, dtype=torch.int32)], 1) if na > 1 else a1
+        from roborugby_amd import players
+        return players.chase(pipe.envs[i], obs, step=s + 1, noise=0.1, seed=1234)
 
-    pipe.reset()
+    obs0 = pipe.reset()
+    for i in range(P):
+        with torch.cuda.stream(pipe.streams[i]):
+            outs[i][0].copy_(obs0[i])
     torch.cuda.synchronize()
     pipe.run(policy, W, outs=outs)
     torch.cuda.synchronize()
     cnt0 = sum(int(e.episode_stats()[3].sum().item()) for e in pipe.envs)
+    # budgeted step: every call's status row is kept and the NOT_READY rows are subtracted afterwards (no extra launch)
+    hist = [torch.zeros(K, n, dtype=torch.int32, device=dev) for _ in range(P)] if args.budget else None
+    step_no[:] = [W] * P
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pipe.run(policy, K, outs=outs)
+    pipe.run(policy, K, outs=(lambda i, s: outs[i][:5] + (hist[i][s],)) if args.budget else outs)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     cnt1 = sum(int(e.episode_stats()[3].sum().item()) for e in pipe.envs)
     resets = cnt1 - cnt0 - sum(int(o[2].sum().item()) for o in outs)
-    steps = N * K - max(resets, 0)
+    n_not_ready = sum(int(((h & 16384) != 0).sum().item()) for h in hist) if args.budget else 0
+    steps = N * K - max(resets, 0) - n_not_ready
     bytes_per_step = p.algorithmic_bytes_per_step(na)
     achieved = bytes_per_step * steps / dt / 1e9
     lanes = pipe.envs[0].lanes_per_env()
@@ -178,7 +176,8 @@ def pipelined(args):
                                    f"different shards overlap), SimpleDuel3 preset {args.preset}, {args.policy}-policy rollout, "
                                    f"{na} action(s)/arena, auto-reset on done, {lanes} lanes per arena",
                        "arenas_per_gpu": N, "preset": args.preset, "policy": args.policy, "lanes_per_arena": lanes,
-                       "sharding": "single GPU", "steps_per_launch": 1, "pipeline": P},
+                       "sharding": "single GPU", "steps_per_launch": 1, "pipeline": P, "step_budget_clocks": args.budget,
+                       "not_ready_fraction": n_not_ready / float(N * K)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "k_step", "kernel_ms": None,
                          "algorithmic_bytes_per_env_step": bytes_per_step, "record_bytes_per_env": pipe.envs[0].state_bytes_per_env(),
@@ -216,14 +215,19 @@ def main():
            torch.empty(n, 11, device=dev) if p.nr_grumpy else None, torch.empty(n, device=dev),
            torch.empty(n, dtype=torch.int32, device=dev))
 
-    def one_step(i):
+    from roborugby_amd import players
+    chase_out = torch.empty(n, na, dtype=torch.int32, device=dev)
+    chase_step = [0]
+
+    out[0].copy_(obs)
+
+    def one_step(i, o=None):
         if args.policy == "random":
             a = acts[i]
-        else:
-            a1 = chase_actions(out[0] if i else obs, 0.1, gen).view(n, 1)
-            a = torch.cat([a1, torch.randint(0, 8, (n, na - 1), generator=gen, device=dev, dtype=torch.int32)], 1) \
-                if na > 1 else a1
-        return env.step(a, out=out)
+        else:  # the scripted on-device policy (one launch, rr_policy_chase): robot 0 chases its ball, 10 % random, the rest random
+            chase_step[0] += 1
+            a = players.chase(env, out[0], step=chase_step[0], noise=0.1, seed=1234 + rank, out=chase_out)
+        return env.step(a, out=out if o is None else o)
 
     stagger = not args.no_stagger and args.fuse == 1
     if stagger:
@@ -261,18 +265,16 @@ def main():
     # the ONE collective of the path: finished-episode returns, all-gathered for logging every min(log_interval, K) steps
     # (the driver runs --steps 20: with the default interval of 25 the loop alone would never issue it)
     gather_every = max(F, min(args.log_interval, K) // F * F)
-    not_ready = torch.zeros(n, dtype=torch.int32, device=dev)
+    status_hist = torch.zeros(K, n, dtype=torch.int32, device=dev) if args.budget else None
     for i in range(0, K, F):
         ev[i][0].record()
         if F > 1:
             env.rollout(acts[W + i:W + i + F], out=fout)  # F steps per launch
-        elif args.policy == "random":
+        elif args.policy == "random" and not args.budget:
             env.step(acts[W + i], out=out)  # k_step (+ the few-microsecond k_order that sorts the next dispatch) between the two events
-        else:
-            one_step(W + i)
+        else:  # (budgeted: every call's status row is kept, the NOT_READY rows are counted after the loop -- no extra launch)
+            one_step(W + i, out[:5] + (status_hist[i],) if args.budget else None)
         ev[i][1].record()
-        if args.budget:
-            not_ready += (out[5] >> 14) & 1  # parked arenas of this call: not env steps
         if world > 1 and (i + F) % gather_every == 0:
             lr = env.episode_stats()[0]
             pending.append(rrd.all_gather_returns(lr, async_op=True))
@@ -290,7 +292,9 @@ def main():
     _, _, _, cnt1 = env.episode_stats()
     last_done = fout[2][-1] if F > 1 else out[2]  # arenas that finished in the very last step are re-placed by a later call
     resets = int((cnt1 - cnt0).sum().item()) - int(last_done.sum().item())
-    n_not_ready = int(not_ready.sum().item())
+    n_not_ready = int(((status_hist & 16384) != 0).sum().item()) if args.budget else 0
+    if args.budget:
+        out = out[:5] + (status_hist[K - 1],)
     local_steps = n * K - max(resets, 0) - n_not_ready
     total_steps = rrd.reduce_sum(float(local_steps), dev)
     kern_ms = sum(ev[i][0].elapsed_time(ev[i][1]) for i in range(0, K, F)) / (K // F)  # per launch

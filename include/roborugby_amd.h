@@ -194,6 +194,15 @@ int rr_goal_scores(rr_env *env, int32_t *scores, void *stream);
 int rr_episode_stats(rr_env *env, float *last_return, float *last_return_g, int32_t *last_len,
                      int32_t *episodes_done, void *stream);
 
+/* Scripted on-device policy of the contact-rich benchmark stream (the reference's scripted players
+ * live in robo_rugby/gym_env/RR_Players.py): robot 0 of every arena turns toward its ball (observation values 0 and 1:
+ * bot angle, ball angle) or drives forward when within 8 degrees, and with probability `noise` takes a random action; robots
+ * 1..na-1 act at random.  obs [N,11] f32 (the rows rr_step / rr_reset wrote), actions [N,na] i32.  The random draws are a
+ * function of (seed, global arena id, step index) only; the step index is step_of[arena] when step_of != NULL (per-arena
+ * counters, e.g. "steps accepted so far" under the budgeted step), else `step`.  One launch, nothing else. */
+int rr_policy_chase(rr_env *env, const float *obs, const int32_t *step_of, uint32_t step, float noise, uint64_t seed,
+                    int32_t *actions, int32_t na, void *stream);
+
 /* Introspection used by bench.py for the roofline line: bytes of the per-arena HBM record, and how many lanes of
  * a wavefront work on one arena (64 = one wavefront per arena; smaller = several arenas packed per wavefront). */
 int rr_state_bytes_per_env(const rr_env *env, int64_t *bytes);

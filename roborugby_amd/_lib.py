@@ -56,6 +56,7 @@ SYMBOLS = {
     "rr_get_episode_state": (C.c_int, [_vp, _vp, _vp, _vp]),
     "rr_set_episode_state": (C.c_int, [_vp, _vp, _vp, _vp]),
     "rr_episode_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "rr_policy_chase": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_float, C.c_uint64, _vp, C.c_int32, _vp]),
     "rr_state_bytes_per_env": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "rr_lanes_per_env": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
 }

@@ -10,8 +10,10 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "rr_kernels.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "rr_sim.hpp"), os.path.join(HERE, "csrc", "rr_extras.hpp"),
-        os.path.join(os.path.dirname(HERE), "include", "roborugby_amd.h")]
+SRC_KSTEP = os.path.join(HERE, "csrc", "rr_kstep_inst.hip")  # explicit instantiations of the step kernel, one share per -DRR_PART
+KSTEP_PARTS = 7                                                # == RR_KSTEP_PARTS in csrc/rr_kstep.hpp
+DEPS = [SRC, SRC_KSTEP, os.path.join(HERE, "csrc", "rr_kstep.hpp"), os.path.join(HERE, "csrc", "rr_sim.hpp"),
+        os.path.join(HERE, "csrc", "rr_extras.hpp"), os.path.join(os.path.dirname(HERE), "include", "roborugby_amd.h")]
 LIB = os.path.join(HERE, "libroborugby_amd.so")
 STAMP = LIB + ".srchash"
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
@@ -43,16 +45,39 @@ def is_stale():
         return f.read().strip() != source_hash()
 
 
-def build_hip_library(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 ... -> libroborugby_amd.so (cross-compiles without a GPU)."""
+def build_hip_library(force=False, verbose=False, jobs=None):
+    """hipcc --offload-arch=gfx950 ... -> libroborugby_amd.so (cross-compiles without a GPU).
+
+    The step kernel's instantiations (14 configurations x up to five variants: most of the compile time) are compiled as
+    KSTEP_PARTS objects next to the main translation unit, in parallel, and linked into the one shared library; no relocatable
+    device code (every kernel is self-contained, csrc/rr_kstep.hpp).  RR_BUILD_JOBS / `jobs` bounds the parallelism."""
     if not force and not is_stale():
         return LIB
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
     digest = source_hash()
-    tmp = LIB + f".tmp{os.getpid()}"
-    cmd = [find_hipcc()] + HIPCC_FLAGS + ["-o", tmp, SRC]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    hipcc = find_hipcc()
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    jobs = jobs or int(os.environ.get("RR_BUILD_JOBS", "0")) or min(8, os.cpu_count() or 1)
+    with tempfile.TemporaryDirectory(prefix="rr_build_") as tmpd:
+        units = [(SRC, ["-DRR_SPLIT_BUILD"], os.path.join(tmpd, "rr_kernels.o"))]
+        units += [(SRC_KSTEP, [f"-DRR_PART={k}"], os.path.join(tmpd, f"rr_kstep_{k}.o")) for k in range(KSTEP_PARTS)]
+
+        def compile_one(u):
+            src, defs, obj = u
+            cmd = [hipcc] + cflags + defs + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            return obj
+
+        with ThreadPoolExecutor(max_workers=jobs) as ex:
+            objs = list(ex.map(compile_one, units))
+        tmp = LIB + f".tmp{os.getpid()}"
+        cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     os.replace(tmp, LIB)  # atomic: a concurrent loader sees the old or the new library, never half of one
     with open(STAMP, "w") as f:
         f.write(digest + "\n")

@@ -22,138 +22,11 @@
 #include "../../include/roborugby_amd.h"
 #include "rr_sim.hpp"
 #include "rr_extras.hpp"
+#include "rr_kstep.hpp"
 
 using namespace rr;
 
-// ------------------------------------------------------------------------------------------------ device side
-template <class C> __device__ __forceinline__ void load_record(Arena<C> &A, const typename C::Real *rec, const int32_t *irec) {
-    using R = typename C::Real;
-    R *p = reinterpret_cast<R *>(&A.p);
-    int32_t *q = reinterpret_cast<int32_t *>(&A.i);
-    const int lane = threadIdx.x & (C::VW - 1);
-    for (int k = lane; k < Arena<C>::P_REALS; k += C::VW) p[k] = rec[k];
-    for (int k = lane; k < Arena<C>::I_INTS; k += C::VW) q[k] = irec[k];
-    RR_SYNC();
-}
-template <class C> __device__ __forceinline__ void store_record(const Arena<C> &A, typename C::Real *rec, int32_t *irec) {
-    using R = typename C::Real;
-    const R *p = reinterpret_cast<const R *>(&A.p);
-    const int32_t *q = reinterpret_cast<const int32_t *>(&A.i);
-    const int lane = threadIdx.x & (C::VW - 1);
-    RR_SYNC();
-    for (int k = lane; k < Arena<C>::P_REALS; k += C::VW) rec[k] = p[k];
-    // the ints and the record's padding: the whole 64-B tail is written, so no line of the record is left partially
-    // dirty (a partial line costs a read-for-merge in L2: 0.3 KB per env-step showed up in FETCH_SIZE)
-    constexpr int TAIL = Arena<C>::I_STRIDE - Arena<C>::P_REALS * Arena<C>::WR;
-    for (int k = lane; k < TAIL; k += C::VW) irec[k] = k < Arena<C>::I_INTS ? q[k] : 0;
-}
-
-#ifndef RR_MIN_WAVES_PER_SIMD
-#define RR_MIN_WAVES_PER_SIMD 4 // upper bound of the occupancy asked from the register allocator (<=128 VGPRs)
-#endif
-#ifndef RR_WAVES_PER_BLOCK
-#define RR_WAVES_PER_BLOCK 1 // arenas never cooperate across wavefronts, so a workgroup IS a wavefront (finer dispatch: +9 % measured)
-#endif
-constexpr int WAVES_PER_BLOCK = RR_WAVES_PER_BLOCK;
-#ifdef RR_ARENAS_PER_WAVE // occupancy probe only: fewer arenas per wavefront (idle lanes) so that LDS admits a third wave per SIMD
-template <class C> constexpr int arenas_per_block() { return (C::VW == 8 ? RR_ARENAS_PER_WAVE : 64 / C::VW) * WAVES_PER_BLOCK; }
-#else
-template <class C> constexpr int arenas_per_block() { return 64 * WAVES_PER_BLOCK / C::VW; }
-#endif
-// Waves per SIMD the 160 KiB of LDS admit for this configuration.  Asking the register allocator for more than that
-// (launch bounds) only buys spills: with 17 KB of LDS per wavefront G/VW=8 and T/VW=2 top out at 2 waves/SIMD, and
-// capping them at 128 VGPRs put ~30 scratch round trips into every sub-step (measured: 487 VMEM instructions per
-// wave-step instead of ~90, and a 0.25 ms latency floor per launch).
-template <class C> constexpr int lds_waves_per_simd() {
-#ifdef RR_FORCE_WAVES // occupancy experiments only (tools/kernel_resources.py ... -DRR_FORCE_WAVES=3)
-    return RR_FORCE_WAVES;
-#endif
-    constexpr int per_cu = (160 * 1024) / (int)(sizeof(Arena<C>) * arenas_per_block<C>()) * WAVES_PER_BLOCK;
-    return per_cu / 4 < 1 ? 1 : (per_cu / 4 > RR_MIN_WAVES_PER_SIMD ? RR_MIN_WAVES_PER_SIMD : per_cu / 4);
-}
-
-
-// MULTI = false: rr_step, one step per launch (nsteps, repeat unused); true: rr_rollout's loop over nsteps.  Separate
-// instantiations: the loop around step_arena costs the single-step kernel 12 % (measured) through register allocation alone.
-// BUDGET = true: the budgeted step (rr_sim.hpp: ParkCtx) -- a separate instantiation, so the default kernel carries none of it.
-template <class C, typename O, bool MULTI, bool BUDGET = false>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void k_step(SimParams<typename C::Real> sp, typename C::Real *recs,
-                                                              int32_t *irecs, int n, const int32_t *actions,
-                                                              const float *thrust, int na, O *obs, O *reward,
-                                                              uint8_t *done, O *obs_g, O *reward_g, int32_t *status,
-                                                              const uint32_t *order, uint32_t *cost, int nsteps, int repeat,
-                                                              uint32_t *snap, int32_t *isnap, uint32_t *park = nullptr,
-                                                              uint32_t budget = 0) {
-    static_assert(!(MULTI && BUDGET), "rr_rollout keeps the record in LDS across steps: no barrier to budget");
-#ifdef RR_FAKE_LDS_ARENAS // resource experiments only (never run): what the register allocator does when LDS stops capping the occupancy
-    __shared__ Arena<C> lds[RR_FAKE_LDS_ARENAS];
-#else
-    __shared__ Arena<C> lds[arenas_per_block<C>()];
-#endif
-    const int wave = threadIdx.x / C::VW; // virtual wave = arena slot in this workgroup
-#ifdef RR_ARENAS_PER_WAVE
-    if (wave >= arenas_per_block<C>()) return;
-#endif
-    // slowest-first dispatch: workgroup b steps the group of arenas that was the b-th slowest in the previous step
-    const unsigned long long t_begin = (cost || BUDGET) ? __builtin_amdgcn_s_memtime() : 0ull;
-    const int group = order ? (int)order[blockIdx.x] : (int)blockIdx.x;
-    const int arena = group * arenas_per_block<C>() + wave;
-    if (arena >= n) return; // uniform per virtual wave; no workgroup barrier is ever used
-    Arena<C> &A = lds[wave];
-    typename C::Real *rec = recs + (size_t)arena * Arena<C>::P_STRIDE;
-    int32_t *irec = irecs + (size_t)arena * Arena<C>::I_STRIDE;
-    RR_T0();
-#if defined(RR_PROFILE_PHASES)
-    const unsigned long long rr_wave_t0_ = __builtin_amdgcn_s_memrealtime(); // 100 MHz, one base for the whole chip
-#endif
-    load_record(A, rec, irec);
-    derive(A, sp);
-    RR_STAMP(12);
-    if constexpr (!MULTI) {
-        StepOut<O> o = { obs, obs_g, reward, reward_g, done, status, sp.memo ? snap : nullptr, isnap, arena,
-                         (int)Arena<C>::SNAP_WORDS, (int)Arena<C>::ISNAP_WORDS };
-        if constexpr (BUDGET) {
-            ParkCtx pk;
-            pk.buf = park + (size_t)arena * Arena<C>::PARK_WORDS; pk.budget = budget; pk.t_begin = t_begin;
-            step_arena<C, O, true>(A, sp, sp.arena_offset + (uint64_t)arena, actions ? actions + (size_t)arena * na : nullptr,
-                                   thrust ? thrust + (size_t)arena * 2 * na : nullptr, na, o, pk);
-        } else {
-            step_arena<C, O>(A, sp, sp.arena_offset + (uint64_t)arena, actions ? actions + (size_t)arena * na : nullptr,
-                             thrust ? thrust + (size_t)arena * 2 * na : nullptr, na, o);
-        }
-    } else {
-        // nsteps consecutive GameEnv.step calls on the record held in LDS (rr_rollout): step s reads its actions at
-        // [s][arena] (or the same ones again when `repeat`) and writes its outputs at [s][arena]
-#pragma unroll 1
-        for (int s = 0; s < nsteps; s++) {
-            const size_t so = (size_t)s * (size_t)n;
-            StepOut<O> o = { obs + so * 11, obs_g ? obs_g + so * 11 : nullptr, reward + so, reward_g ? reward_g + so : nullptr, done + so,
-                             status ? status + so : nullptr, sp.memo ? snap : nullptr, isnap, arena,
-                             (int)Arena<C>::SNAP_WORDS, (int)Arena<C>::ISNAP_WORDS };
-            const size_t ao = repeat ? 0 : so;
-            step_arena<C, O>(A, sp, sp.arena_offset + (uint64_t)arena, actions ? actions + (ao + (size_t)arena) * na : nullptr,
-                             thrust ? thrust + (ao + (size_t)arena) * 2 * na : nullptr, na, o);
-        }
-    }
-    RR_TR();
-    {   // the record addresses again, from an arena index the optimiser cannot tie to the first one: otherwise the two
-        // 64-bit pointers stay live across the whole step (4 VGPRs of a kernel that sits at the 256-VGPR limit)
-        int arena_again = arena;
-        asm volatile("" : "+v"(arena_again));
-        store_record(A, recs + (size_t)arena_again * Arena<C>::P_STRIDE, irecs + (size_t)arena_again * Arena<C>::I_STRIDE);
-    }
-    RR_STAMP(13);
-    if (cost && threadIdx.x == 0) { // what this group cost, in shader clocks / 256 (saturating): next step's dispatch key
-        const unsigned long long dt = ((__builtin_amdgcn_s_memtime() - t_begin) >> 8) / (unsigned)(MULTI ? nsteps : 1); // per step
-        cost[group] = dt > 0xFFFFull ? 0xFFFFu : (uint32_t)dt;
-    }
-#if defined(RR_PROFILE_PHASES)
-    if ((threadIdx.x & 63) == 0 && blockIdx.x < 65536) {
-        g_rr_wave_t[2 * blockIdx.x] = rr_wave_t0_;
-        g_rr_wave_t[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-    }
-#endif
-}
+// (load_record / store_record / k_step and the list of built configurations: rr_kstep.hpp, shared with rr_kstep_inst.hip)
 
 // Slowest-first order for the next launch (longest-processing-time-first list scheduling).  A launch ends when its
 // slowest wavefront does and wavefronts differ 3x and more in duration (contact-rich arenas); dispatched in index order a
@@ -413,21 +286,26 @@ __global__ void k_observe_kind(SimParams<typename C::Real> sp, const typename C:
     for (int k = 0; k < dim; k++) obs[(size_t)a * dim + k] = k < m ? tmp[k] : (O)NAN;
 }
 
-// ------------------------------------------------------------------------------------------------ host side
-// Built configurations: (kind = shape + 2*dtype, entity counts, Real, VW).  The first VW listed for a kind is the
-// default; the environment variable RR_VW selects another built width (kernel tuning / A-B runs).
-#if defined(RR_CFG_SUBSET) && RR_CFG_SUBSET == 2 // occupancy probe: T at 4 lanes per arena (its LDS admits 4 waves per SIMD)
-#define RR_FOR_EACH_CFG(X) X(0, 1, 0, 1, 0, double, 4) X(1, 2, 2, 4, 4, double, 8)
-#elif defined(RR_CFG_SUBSET) // tuning builds only (tools/build_variant.sh): the two default configurations, quick to compile
-#define RR_FOR_EACH_CFG(X) X(0, 1, 0, 1, 0, double, 2) X(1, 2, 2, 4, 4, double, 8)
-#else
-#define RR_FOR_EACH_CFG(X)                                                                             \
-    X(0, 1, 0, 1, 0, double, 2) X(0, 1, 0, 1, 0, double, 4) X(0, 1, 0, 1, 0, double, 8) X(0, 1, 0, 1, 0, double, 64) \
-    X(1, 2, 2, 4, 4, double, 8) X(1, 2, 2, 4, 4, double, 16) X(1, 2, 2, 4, 4, double, 32) X(1, 2, 2, 4, 4, double, 64) \
-    X(2, 1, 0, 1, 0, float, 2) X(2, 1, 0, 1, 0, float, 4) X(2, 1, 0, 1, 0, float, 64)                                 \
-    X(3, 2, 2, 4, 4, float, 8) X(3, 2, 2, 4, 4, float, 16) X(3, 2, 2, 4, 4, float, 64)
-#endif
+// Scripted on-device policy of the contact-rich workload ("turn toward ball_angle, else forward, 10 %
+// random"): robot 0 of every arena chases its ball from the arena's own observation row, the other robots act at random.
+// One thread per arena, counter-based RNG keyed by (seed, global arena id, step) -- the policy is a function of the arena's
+// observation and of the step index the caller passes, nothing else (so it is the same whatever the batch is doing around it).
+__global__ void k_policy_chase(const float *obs, int n, int na, uint32_t noise_u32, uint64_t seed, uint64_t arena_offset,
+                               const int32_t *step_of, uint32_t step, int32_t *actions) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    const float d = fmodf(obs[(size_t)a * 11 + 1] - obs[(size_t)a * 11 + 0] + 540.0f, 360.0f) - 180.0f;
+    int act = fabsf(d) < 8.0f ? 0 : (d > 0.0f ? 2 : 3); // FORWARD / LEFT / RIGHT (RR_EnvBase.py:583-591)
+    const uint64_t gid = arena_offset + (uint64_t)a;
+    const uint32_t st = step_of ? (uint32_t)step_of[a] : step;
+    uint32_t c[4] = { (uint32_t)gid, (uint32_t)(gid >> 32), st, 0x70C1u };
+    philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    if (c[0] < noise_u32) act = (int)(c[1] & 7u);
+    actions[(size_t)a * na] = act;
+    for (int k = 1; k < na; k++) actions[(size_t)a * na + k] = (int)((c[2 + (k & 1)] >> (4 * (k >> 1))) & 7u);
+}
 
+// ------------------------------------------------------------------------------------------------ host side
 struct rr_env {
     rr_config cfg;
     int kind; // 0 T64, 1 G64, 2 T32, 3 G32
@@ -999,6 +877,21 @@ int rr_episode_stats(rr_env *e, float *lr, float *lrg, int32_t *ll, int32_t *cnt
     HIP_TRY(hipGetLastError());
     return 0;
 }
+int rr_policy_chase(rr_env *e, const float *obs, const int32_t *step_of, uint32_t step, float noise, uint64_t seed, int32_t *actions,
+                    int32_t na, void *stream) {
+    if (!e || !obs || !actions) return fail(-1, "rr_policy_chase: null argument");
+    const int nr = e->cfg.nr_happy + e->cfg.nr_grumpy;
+    if (na < 1 || na > nr || na > 8) return fail(-1, "rr_policy_chase: between 1 action and one per robot");
+    if (!(noise >= 0.0f && noise <= 1.0f)) return fail(-1, "rr_policy_chase: noise must be in [0, 1]");
+    const int n = e->cfg.num_envs;
+    DeviceGuard guard(e->cfg.device);
+    const uint32_t nz = noise >= 1.0f ? 0xFFFFFFFFu : (uint32_t)((double)noise * 4294967296.0);
+    hipLaunchKernelGGL(k_policy_chase, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, obs, n, (int)na, nz, seed,
+                       e->cfg.arena_offset, step_of, step, actions);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int rr_state_bytes_per_env(const rr_env *e, int64_t *bytes) {
     if (!e || !bytes) return fail(-1, "rr_state_bytes_per_env: null argument");
     *bytes = (int64_t)(e->rec_bytes + e->irec_bytes);

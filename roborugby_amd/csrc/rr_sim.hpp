@@ -2266,6 +2266,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     int f0 = 0; // first sub-step to run: 0, or where a parked step goes on
     constexpr bool FZP = C::NR <= 4 && C::NB <= 8; // what the packed word holds
     bool resumed = false;
+    RR_T0();
     if constexpr (BUDGET) {
         resumed = A.i.fzp < 0; // uniform per arena (read after load_record's sync)
         if (RR_UNLIKELY(resumed)) {
@@ -2306,7 +2307,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
         }
         return;
     }
-    RR_T0();
+    RR_TR();
     // ---- on_step_begin (:264-265; sprites, then the score keepers RR_ScoreKeepers.py:30-33,119-121,145-147)
     static_assert(C::NBP + C::NR * C::NBP <= 2 * 3 * C::NR, "reward scratch reuses the lidar slots");
     // _calc_ball_dist_sum (RR_ScoreKeepers.py:155-157): one lane per positive ball, summed in list order below

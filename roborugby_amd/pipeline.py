@@ -42,12 +42,13 @@ class ShardedPipeline:
     def run(self, policy, steps, on_step=None, outs=None):
         """`steps` env steps of every shard.  policy(shard_index, obs[n,11]) -> actions for that shard, called with the shard's
         stream current (everything it enqueues runs there); on_step(shard_index, step, obs, reward, done, info) likewise.
+        `outs`: per-shard preallocated output tuples, or a callable (shard_index, step) -> tuple (e.g. a fresh status row per step).
         No host synchronisation happens here: call synchronize() (or wait on the streams) before reading results elsewhere."""
         for s in range(steps):
             for i, e in enumerate(self.envs):
                 with torch.cuda.stream(self.streams[i]):
                     a = policy(i, self.obs[i])
-                    res = e.step(a, out=outs[i] if outs is not None else None)
+                    res = e.step(a, out=(outs(i, s) if callable(outs) else outs[i]) if outs is not None else None)
                     self.obs[i], self.last[i] = res[0], res
                     if on_step is not None:
                         on_step(i, s, *res)

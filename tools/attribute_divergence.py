@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Which arithmetic difference makes the kernel leave the reference's trajectory, and where.
+
+The HIP kernel differs from the reference in exactly two places: its own sin/cos (< 1 ulp from glibc's) and the centre of the
+module-global scratch rect `_rectBallInner` (RR_TrashyPhysics.py:54,94,165: carried as c_old + (c_new - c_old); the kernel uses
+the ball centre).  The CPU oracle is bit-exact to the reference's golden episodes; with `rro_debug_attribution` it makes either
+substitution (or both), so free-running every golden episode under each variant shows which one causes the first departure:
+
+  variant 0 = reference arithmetic (must track every episode to its end, bit for bit)
+  variant 1 = scratch-rect centre := ball centre        variant 2 = the kernel's sin/cos        variant 3 = both
+  kernel    = the kernel's own phase source (host-emulated wave; on the GPU only atan -- observations, never state -- differs)
+
+For the first step where ANY state bit differs from the golden, the sub-step is bisected (both sides run k = 1..12 sub-steps
+from the golden pre-step state) and the size of the difference is reported in ulps of the value.  No GPU.
+usage: python tools/attribute_divergence.py [T|G|both] > profiles/r03/divergence_attribution.txt"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import emu_lib as el  # noqa: E402
+import oracle_lib as ol  # noqa: E402
+
+
+def ulps(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    m = np.isfinite(a) & np.isfinite(b) & (a != b)
+    if not m.any():
+        return 0.0
+    sp = np.spacing(np.maximum(np.abs(a[m]), np.abs(b[m])))
+    return float(np.max(np.abs(a[m] - b[m]) / sp))
+
+
+def state_equal(s, t, ep, k):
+    return (np.array_equal(s["robots"], t["state_robots"][ep, k], equal_nan=True) and np.array_equal(s["balls"], t["state_balls"][ep, k])
+            and np.array_equal(s["robots_i"], t["state_robots_i"][ep, k]))
+
+
+def free_run(make_env, t, ep, na):
+    """first step index whose post-state differs from the golden (None: tracks to the end)"""
+    env = make_env()
+    env.set_state(t["state_robots"][ep, 0], t["state_robots_i"][ep, 0], t["state_balls"][ep, 0], *( [t["state_inner"][ep, 0]] if hasattr(env, "nr") and isinstance(env, ol.OracleEnv) else []), step=int(t["state_step"][ep, 0]))
+    L = int(t["length"][ep])
+    for s in range(L):
+        a = np.clip(t["actions"][ep, s, :na], 0, 7).astype(np.int32)
+        env.step(a)
+        if not state_equal(env.get_state(), t, ep, s + 1):
+            return s
+    return None
+
+
+def bisect_substep(flags, t, ep, s, na, kernel=False):
+    """sub-step (0..11) of step s after which the variant first differs from the reference arithmetic, both started from the
+    golden pre-step state; + the largest difference in ulps at that point and which entity field carries it"""
+    a = np.clip(t["actions"][ep, s, :na], 0, 7).astype(np.int32)
+    pre = (t["state_robots"][ep, s], t["state_robots_i"][ep, s], t["state_balls"][ep, s])
+    preset = t["_preset"]
+    for k in range(1, 13):
+        ol.lib().rro_debug_set_substeps(k)
+        el.lib().emu_debug_set_substeps(k)
+        try:
+            ol.lib().rro_debug_attribution(0)
+            ref = ol.OracleEnv(preset)
+            ref.set_state(*pre, t["state_inner"][ep, s], int(t["state_step"][ep, s]))
+            ref.step(a)
+            r = ref.get_state()
+            if kernel:
+                v = el.EmuEnv(preset)
+                v.set_state(*pre, step=int(t["state_step"][ep, s]))
+            else:
+                ol.lib().rro_debug_attribution(flags)
+                v = ol.OracleEnv(preset)
+                v.set_state(*pre, t["state_inner"][ep, s], int(t["state_step"][ep, s]))
+            v.step(a)
+            g = v.get_state()
+        finally:
+            ol.lib().rro_debug_set_substeps(12)
+            el.lib().emu_debug_set_substeps(12)
+            ol.lib().rro_debug_attribution(0)
+        if not (np.array_equal(g["robots"], r["robots"], equal_nan=True) and np.array_equal(g["balls"], r["balls"])):
+            ur, ub = ulps(g["robots"], r["robots"]), ulps(g["balls"], r["balls"])
+            names_r = ["cx", "cy", "left", "right", "top", "bottom", "rot", "prev_x", "prev_y", "prev_rot"]
+            names_b = ["cx", "cy", "left", "right", "top", "bottom", "vx", "vy"]
+            dr = np.nan_to_num(np.abs(g["robots"] - r["robots"])); db = np.abs(g["balls"] - r["balls"])
+            if dr.max() >= db.max():
+                i = np.unravel_index(np.argmax(dr), dr.shape); where = f"robot {i[0]} {names_r[i[1]]}"
+            else:
+                i = np.unravel_index(np.argmax(db), db.shape); where = f"ball {i[0]} {names_b[i[1]]}"
+            return k - 1, max(ur, ub), where, float(max(dr.max(), db.max()))
+    return None
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "both"
+    for preset in (("T", "G") if which == "both" else (which,)):
+        t = dict(np.load(os.path.join(ROOT, "tests", "golden", f"traj_{preset}.npz"), allow_pickle=False))
+        t["_preset"] = preset
+        na_used = (t["actions"][:, 0, :] >= 0).sum(1)
+        full = np.nonzero(na_used == na_used.max())[0]
+        na = int(na_used.max())
+        print(f"== preset {preset}: {len(full)} free-running golden episodes (every robot driven), first step whose state differs from the reference's")
+        print(f"{'episode':>7} {'length':>6} | {'ref-arith':>9} {'no-carry':>9} {'k-sincos':>9} {'both':>9} {'kernel':>9} | first cause, sub-step, where, size")
+        tally = {"sincos": 0, "carry": 0, "none": 0}
+        for ep in full:
+            res = []
+            for flags in (0, 1, 2, 3):
+                ol.lib().rro_debug_attribution(flags)
+                try:
+                    res.append(free_run(lambda: ol.OracleEnv(preset), t, ep, na))
+                finally:
+                    ol.lib().rro_debug_attribution(0)
+            res.append(free_run(lambda: el.EmuEnv(preset), t, ep, na))
+            assert res[0] is None, f"the reference arithmetic itself leaves golden episode {ep} at step {res[0]}"
+            L = int(t["length"][ep])
+            f = lambda x: "-" if x is None else str(x)
+            cause = ""
+            if res[4] is not None:
+                c1, c2 = res[1], res[2]
+                first = "sincos" if (c2 is not None and (c1 is None or c2 <= c1)) else "carry"
+                tally[first] += 1
+                b = bisect_substep(2 if first == "sincos" else 1, t, ep, res[2] if first == "sincos" else res[1], na)
+                bk = bisect_substep(0, t, ep, res[4], na, kernel=True)
+                cause = f"{first}: step {res[2] if first == 'sincos' else res[1]}"
+                if b:
+                    cause += f" sub-step {b[0]}, {b[2]}, {b[1]:.1f} ulp ({b[3]:.2e})"
+                if bk:
+                    cause += f" | kernel: step {res[4]} sub-step {bk[0]}, {bk[2]}, {bk[1]:.1f} ulp ({bk[3]:.2e})"
+            else:
+                tally["none"] += 1
+            print(f"{ep:>7} {L:>6} | {f(res[0]):>9} {f(res[1]):>9} {f(res[2]):>9} {f(res[3]):>9} {f(res[4]):>9} | {cause}")
+        print(f"   first cause of the kernel's bit-level departures: {tally}")
+        print("   ('-' = tracks the reference bit for bit to the last step; a bit-level departure is not yet a 1e-9 departure:")
+        print("    the GPU test counts episodes whose observations stay within 1e-9, tests/test_gpu_parity.py)")
+
+
+if __name__ == "__main__":
+    main()

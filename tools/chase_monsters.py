@@ -11,8 +11,9 @@ preset = sys.argv[1] if len(sys.argv) > 1 else "G"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 warm = int(sys.argv[3]) if len(sys.argv) > 3 else 150
 policy = sys.argv[4] if len(sys.argv) > 4 else "chase"
+budget = int(sys.argv[5]) if len(sys.argv) > 5 else 0  # the budgeted step (shader clocks), 0 = synchronous
 n = 65536
-env = rr.BatchedRoboRugbyEnv(n, preset=preset, seed=0)
+env = rr.BatchedRoboRugbyEnv(n, preset=preset, seed=0, step_budget_clocks=budget)
 obs = env.reset()
 lib = _lib.load()
 na = env.preset.nr
