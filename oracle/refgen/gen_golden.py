@@ -26,7 +26,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
-GOLD = os.path.join(REPO, "tests", "golden")
+GOLD = os.environ.get("RR_GOLDEN_OUT") or os.path.join(REPO, "tests", "golden")  # (tests regenerate into a scratch directory)
 sys.path.insert(0, HERE)
 
 META = {
@@ -587,6 +587,10 @@ def alt_observations(R, env):
 
 def gen_mix(R, preset):
     sk, O, base, c = R.sk, R.obs, R.base, R.const
+    # The env constructors place sprites with Python's global `random`, and until the first step AllCoords_WithPrior reports the
+    # stale pre-placement rectDblPriorStep of that construction (alt0_allp_*, row 0 of each mixin stack): seeded here, so that the
+    # part reproduces its file whatever ran before it in the process (row 0 used to depend on the earlier parts).
+    random.seed(90210 + (1 if preset == "G" else 0))
     cnt = Counters(R)  # also turns the reference's endless GAME_MODE warning loop into an exception
     R.envs.SimpleDuel3()  # first constructed env fixes the shared class-level observation_space (Obs:30-37)
 
@@ -675,7 +679,9 @@ def gen_mix(R, preset):
         out["alt0_" + k] = np.stack([e["alt0"][k] for e in eps])
     meta = dict(META, preset=preset, programs_mro=progs, programs_exec={k: exec_order(v) for k, v in progs.items()},
                 keeper_ids=KEEPER_IDS, note="which: 0 = MixA, 1 = MixB; alt observations come from the other observer mixins "
-                "called as unbound methods on the same env state")
+                "called as unbound methods on the same env state",
+                invocation=f"python oracle/refgen/gen_golden.py {preset} mix   (one fresh process per preset; the part seeds "
+                           "Python's global random before it constructs its envs)")
     out["meta"] = np.array(json.dumps(meta))
     np.savez_compressed(os.path.join(GOLD, f"mix_{preset}.npz"), **out)
 

@@ -110,6 +110,11 @@ __device__ unsigned long long g_rr_wave_t[2 * 65536]; // [start, end] s_memtime 
 // rare branches (contact paths, reset, frozen islands): tells the register allocator where spilling is cheap
 #define RR_UNLIKELY(x) __builtin_expect(!!(x), 0)
 
+#ifdef RR_NO_OBS_STAGE // A/B builds only: observation rows written by one lane, value by value
+#define RR_OBS_STAGE 0
+#else
+#define RR_OBS_STAGE 1
+#endif
 #ifndef RR_NUM_SUBSTEPS
 #define RR_NUM_SUBSTEPS 12 // MOVES_PER_FRAME (RR_Constants.py:13); only the emulation harness overrides it to bisect
 #endif
@@ -1819,12 +1824,22 @@ RR_HDN bool observe(Arena<C> &A, const SimParams<typename C::Real> &sp, int team
         goal_angle = py_mod<R>(goal_angle + (R)180, (R)360);
         bot_angle = py_mod<R>(bot_angle + (R)180, (R)360);
     }
+    // The row leaves as ONE lane-strided run per arena (consecutive arenas of a wavefront are consecutive rows: 2 store
+    // instructions per wavefront for eight 44-B rows instead of 11 single-lane ones): lane 0 parks the values in A.lid -- every
+    // lane holds its copy of the six minima by now -- and the arena's lanes write them out side by side.
+    constexpr bool STAGED = RR_GPU && RR_OBS_STAGE && sizeof(A.lid) >= 11 * sizeof(O);
+    if constexpr (STAGED) RR_SYNC();
+    O *row = STAGED ? reinterpret_cast<O *>(&A.lid[0]) : out;
     if (RR_IS_LANE0) {
-        out[0] = (O)bot_angle; out[1] = (O)ball_angle; out[2] = (O)ball_dist; out[3] = (O)goal_angle; out[4] = (O)goal_dist;
+        row[0] = (O)bot_angle; row[1] = (O)ball_angle; row[2] = (O)ball_dist; row[3] = (O)goal_angle; row[4] = (O)goal_dist;
         // lidar_front, front_l, front_r, back, back_l, back_r ; ray1 = (front_l, back_r), ray2 = (front_r, back_l)
-        out[5] = (O)lid[0]; out[6] = (O)lid[2]; out[7] = (O)lid[4]; out[8] = (O)lid[1]; out[9] = (O)lid[5]; out[10] = (O)lid[3];
+        row[5] = (O)lid[0]; row[6] = (O)lid[2]; row[7] = (O)lid[4]; row[8] = (O)lid[1]; row[9] = (O)lid[5]; row[10] = (O)lid[3];
     }
     RR_SYNC();
+    if constexpr (STAGED) {
+        for (int base = 0; base < 11; base += C::VW) { RR_FOR_LANES(l) { if (base + l < 11) out[base + l] = row[base + l]; } }
+        RR_SYNC();
+    }
     return true;
 }
 
@@ -1906,12 +1921,14 @@ RR_HDN void observe_both(Arena<C> &A, const SimParams<typename C::Real> &sp, O *
     }
     RR_SYNC();
     uint64_t any_div0 = 0;
+    constexpr bool STAGED = RR_GPU && RR_OBS_STAGE && sizeof(A.lid) >= 11 * sizeof(O) && sizeof(A.exc) >= 11 * sizeof(O);
     RR_FOR_LANES(l) { // the scalar tails of the two teams, side by side
         int lst = 0;
         if (l < 2) {
             const int ridx = l == 0 ? 0 : C::NRH;
             O *out = l == 0 ? out_h : out_g;
-            const R *lid = lids[l];
+            R lid[6]; // (by value: the team's staged output row reuses this very array below)
+            for (int k = 0; k < 6; k++) lid[k] = lids[l][k];
             V2<R> rc = { A.p.rcx[ridx], A.p.rcy[ridx] }, bc = { A.p.bcx[0], A.p.bcy[0] };
             V2<R> good = { sp.W, sp.H }, bad = { (R)0, (R)0 };
             R ball_angle = angle_degrees<R>(rc, bc, lst);
@@ -1926,13 +1943,26 @@ RR_HDN void observe_both(Arena<C> &A, const SimParams<typename C::Real> &sp, O *
                 goal_angle = py_mod<R>(goal_angle + (R)180, (R)360);
                 bot_angle = py_mod<R>(bot_angle + (R)180, (R)360);
             }
-            out[0] = (O)bot_angle; out[1] = (O)ball_angle; out[2] = (O)ball_dist; out[3] = (O)goal_angle; out[4] = (O)goal_dist;
-            out[5] = (O)lid[0]; out[6] = (O)lid[2]; out[7] = (O)lid[4]; out[8] = (O)lid[1]; out[9] = (O)lid[5]; out[10] = (O)lid[3];
+            // staged (see observe()): each team's row is parked in the array its minima came from -- A.lid / A.exc, read into
+            // registers above by this very lane -- and leaves as lane-strided runs below
+            O *row = STAGED ? reinterpret_cast<O *>(lids[l]) : out;
+            row[0] = (O)bot_angle; row[1] = (O)ball_angle; row[2] = (O)ball_dist; row[3] = (O)goal_angle; row[4] = (O)goal_dist;
+            row[5] = (O)lid[0]; row[6] = (O)lid[2]; row[7] = (O)lid[4]; row[8] = (O)lid[1]; row[9] = (O)lid[5]; row[10] = (O)lid[3];
         }
         RR_VOTE(any_div0, l, (lst & ST_DIV0) != 0);
     }
     if (any_div0) st |= ST_DIV0;
     RR_SYNC();
+    if constexpr (STAGED) {
+        for (int base = 0; base < 22; base += C::VW) {
+            RR_FOR_LANES(l) {
+                const int k = base + l;
+                if (k < 11) out_h[k] = reinterpret_cast<const O *>(lids[0])[k];
+                else if (k < 22) out_g[k - 11] = reinterpret_cast<const O *>(lids[1])[k - 11];
+            }
+        }
+        RR_SYNC();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ derived data, clean poses
