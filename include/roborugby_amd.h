@@ -203,6 +203,40 @@ int rr_episode_stats(rr_env *env, float *last_return, float *last_return_g, int3
 int rr_policy_chase(rr_env *env, const float *obs, const int32_t *step_of, uint32_t step, float noise, uint64_t seed,
                     int32_t *actions, int32_t na, void *stream);
 
+/* ---- config 5 (BASELINE.json): the learn step of the reference's DQN agent (Training_DQN_pytorch.py:25-67 DeepQNetwork
+ * Linear 11 -> 256 -> 256 -> 8 + ReLU, MSELoss, Adam; :151-191 DQNAgent.learn) fused into two launches for the wide batches of the
+ * batched trainer: forward of Q_eval(s) and Q_target(s'), TD target, loss gradient, backward and the weight-gradient reduction in
+ * one kernel (fp32 matrix cores, activations resident in LDS), partial-gradient reduction + Adam in the second
+ * (roborugby_amd/csrc/rr_dqn.hip).  Every pointer is a device pointer; the parameters stay PyTorch's (updated in place), the
+ * handle owns the Adam moments and the scratch.  Same math as torch autograd up to fp32 summation order. */
+typedef struct rr_dqn rr_dqn; /* opaque */
+typedef struct rr_dqn_args {
+    int32_t struct_size;            /* = sizeof(rr_dqn_args) */
+    int32_t batch;                  /* samples per update: a positive multiple of 64 */
+    float *eval_params[6];          /* fc1.weight [256,11], fc1.bias [256], fc2.weight [256,256], fc2.bias [256], fc3.weight [8,256],
+                                       fc3.bias [8] of Q_eval (row-major, torch.nn.Linear layout): updated in place */
+    const float *target_params[6];  /* the same six tensors of Q_target */
+    const float *state_memory;      /* replay memory (Training_DQN_pytorch.py:95-104): [M,11] */
+    const float *new_state_memory;  /* [M,11] */
+    const int64_t *action_memory;   /* [M] */
+    const float *reward_memory;     /* [M] */
+    const uint8_t *terminal_memory; /* [M] (torch.bool) */
+    const int64_t *batch_index;     /* [batch] sampled rows of the memory (NULL: rows 0 .. batch-1) */
+    float gamma, lr, beta1, beta2, eps; /* :79 gamma; torch.optim.Adam defaults 1e-3 / .9 / .999 / 1e-8 unless set (:42 lr) */
+    float *loss_out;                /* nullable: the batch's mean squared TD error (MSELoss) */
+} rr_dqn_args;
+int rr_dqn_create(int32_t device, rr_dqn **out);
+int rr_dqn_destroy(rr_dqn *dqn);
+const char *rr_dqn_last_error(void);
+/* One gradient step: Q_eval's parameters <- Adam(grad of MSE(r + gamma max_a' Q_target(s'), Q_eval(s)[a])). */
+int rr_dqn_update(rr_dqn *dqn, const rr_dqn_args *args, void *stream);
+/* The same gradient without the update: grads [rr_dqn_param_count()] in the order fc2.weight, fc1.weight, fc3.weight, fc1.bias,
+ * fc2.bias, fc3.bias (the parity tests' window). */
+int rr_dqn_grads(rr_dqn *dqn, const rr_dqn_args *args, float *grads, void *stream);
+int32_t rr_dqn_param_count(void);
+/* Adam moments (same order as rr_dqn_grads) and step count out of / into the handle: checkpoint / resume. */
+int rr_dqn_adam_state(rr_dqn *dqn, float *exp_avg, float *exp_avg_sq, int64_t *step, int32_t set, void *stream);
+
 /* Introspection used by bench.py for the roofline line: bytes of the per-arena HBM record, and how many lanes of
  * a wavefront work on one arena (64 = one wavefront per arena; smaller = several arenas packed per wavefront). */
 int rr_state_bytes_per_env(const rr_env *env, int64_t *bytes);

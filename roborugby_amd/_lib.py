@@ -27,6 +27,17 @@ class RRConfig(C.Structure):
     ]
 
 
+class RRDqnArgs(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("batch", C.c_int32),
+        ("eval_params", C.c_void_p * 6), ("target_params", C.c_void_p * 6),
+        ("state_memory", C.c_void_p), ("new_state_memory", C.c_void_p), ("action_memory", C.c_void_p),
+        ("reward_memory", C.c_void_p), ("terminal_memory", C.c_void_p), ("batch_index", C.c_void_p),
+        ("gamma", C.c_float), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("loss_out", C.c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/roborugby_amd.h declares
 _vp = C.c_void_p
 SYMBOLS = {
@@ -57,6 +68,13 @@ SYMBOLS = {
     "rr_set_episode_state": (C.c_int, [_vp, _vp, _vp, _vp]),
     "rr_episode_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "rr_policy_chase": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_float, C.c_uint64, _vp, C.c_int32, _vp]),
+    "rr_dqn_create": (C.c_int, [C.c_int32, C.POINTER(_vp)]),
+    "rr_dqn_destroy": (C.c_int, [_vp]),
+    "rr_dqn_last_error": (C.c_char_p, []),
+    "rr_dqn_update": (C.c_int, [_vp, C.POINTER(RRDqnArgs), _vp]),
+    "rr_dqn_grads": (C.c_int, [_vp, C.POINTER(RRDqnArgs), _vp, _vp]),
+    "rr_dqn_param_count": (C.c_int32, []),
+    "rr_dqn_adam_state": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_int64), C.c_int32, _vp]),
     "rr_state_bytes_per_env": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "rr_lanes_per_env": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
 }

@@ -11,8 +11,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "rr_kernels.hip")
 SRC_KSTEP = os.path.join(HERE, "csrc", "rr_kstep_inst.hip")  # explicit instantiations of the step kernel, one share per -DRR_PART
+SRC_DQN = os.path.join(HERE, "csrc", "rr_dqn.hip")            # fused DQN update (config 5): its own translation unit
 KSTEP_PARTS = 7                                                # == RR_KSTEP_PARTS in csrc/rr_kstep.hpp
-DEPS = [SRC, SRC_KSTEP, os.path.join(HERE, "csrc", "rr_kstep.hpp"), os.path.join(HERE, "csrc", "rr_sim.hpp"),
+DEPS = [SRC, SRC_KSTEP, SRC_DQN, os.path.join(HERE, "csrc", "rr_kstep.hpp"), os.path.join(HERE, "csrc", "rr_sim.hpp"),
         os.path.join(HERE, "csrc", "rr_extras.hpp"), os.path.join(os.path.dirname(HERE), "include", "roborugby_amd.h")]
 LIB = os.path.join(HERE, "libroborugby_amd.so")
 STAMP = LIB + ".srchash"
@@ -62,6 +63,7 @@ def build_hip_library(force=False, verbose=False, jobs=None):
     with tempfile.TemporaryDirectory(prefix="rr_build_") as tmpd:
         units = [(SRC, ["-DRR_SPLIT_BUILD"], os.path.join(tmpd, "rr_kernels.o"))]
         units += [(SRC_KSTEP, [f"-DRR_PART={k}"], os.path.join(tmpd, f"rr_kstep_{k}.o")) for k in range(KSTEP_PARTS)]
+        units += [(SRC_DQN, [], os.path.join(tmpd, "rr_dqn.o"))]
 
         def compile_one(u):
             src, defs, obj = u

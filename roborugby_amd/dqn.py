@@ -22,6 +22,7 @@ reference ties to its step counter is kept PER TRANSITION, so it means the same 
 """
 import argparse
 import copy
+import ctypes as C
 import json
 import math
 import os
@@ -86,7 +87,7 @@ class BatchedDQNAgent:
 
     def __init__(self, gamma=.99, epsilon=1.0, lr=.0005, input_dims=11, batch_size=2500, n_actions=8,
                  max_mem_size=500000, eps_end=0.2, eps_dec=.999997, fc1_dims=256, fc2_dims=256,
-                 target_update_freq=100000, device="cpu", seed=0, use_graph=True):
+                 target_update_freq=100000, device="cpu", seed=0, use_graph=True, fused=None):
         self.gamma, self.epsilon, self.eps_end, self.eps_dec = gamma, epsilon, eps_end, eps_dec
         self.n_actions, self.mem_size, self.batch_size = n_actions, int(max_mem_size), int(batch_size)
         self.target_update_freq = int(target_update_freq)
@@ -111,6 +112,24 @@ class BatchedDQNAgent:
         self.terminal_memory = torch.zeros(m, dtype=torch.bool, device=d)
         self.last_loss = None
         self.use_graph = bool(use_graph)
+        # The fused learn step (include/roborugby_amd.h: rr_dqn_update; csrc/rr_dqn.hip): forward of both nets, TD target,
+        # backward, weight-gradient reduction and Adam in two launches on the fp32 matrix cores -- for exactly this network
+        # (11 -> 256 -> 256 -> 8) on the GPU, batch a multiple of 64.  Default: on whenever it applies.  Off: the PyTorch path
+        # (autograd + torch.optim.Adam), which is also the reference the fused step is tested against.
+        can_fuse = (self.device.type == "cuda" and (input_dims, fc1_dims, fc2_dims, n_actions) == (11, 256, 256, 8)
+                    and self.batch_size % 64 == 0)
+        self.fused = can_fuse if fused is None else bool(fused)
+        if self.fused and not can_fuse:
+            raise ValueError("fused=True needs a GPU, the reference's 11-256-256-8 network and a batch that is a multiple of 64")
+        self._fused_h = None
+        self._lr, self._betas, self._adam_eps = lr, (0.9, 0.999), 1e-8
+        if self.fused:
+            from . import _lib
+            self._rrlib = _lib.load()
+            h = C.c_void_p()
+            _lib.check(self._rrlib.rr_dqn_create(self.device.index or 0, C.byref(h)), "rr_dqn_create")
+            self._fused_h = h
+            self._fused_loss = torch.zeros(1, device=self.device)
 
     @torch.no_grad()
     def choose_action(self, observation, epsilon_override=None):
@@ -147,6 +166,49 @@ class BatchedDQNAgent:
             return torch.randperm(max_mem, generator=self.gen, device=self.device)[:self.batch_size]  # replace=False
         # a multi-million-entry memory: independent draws (two of B draws coincide with probability ~B^2 / 2 max_mem per batch)
         return torch.randint(0, max_mem, (self.batch_size,), generator=self.gen, device=self.device)
+
+    def _fused_args(self, batch):
+        from . import _lib
+        a = _lib.RRDqnArgs()
+        a.struct_size, a.batch = C.sizeof(_lib.RRDqnArgs), int(batch.shape[0])
+        for k, (pe, pt) in enumerate(zip(self.Q_eval.parameters(), self.Q_target.parameters())):
+            assert pe.is_contiguous() and pt.is_contiguous() and pe.dtype == torch.float32
+            a.eval_params[k], a.target_params[k] = pe.data_ptr(), pt.data_ptr()
+        a.state_memory, a.new_state_memory = self.state_memory.data_ptr(), self.new_state_memory.data_ptr()
+        a.action_memory, a.reward_memory = self.action_memory.data_ptr(), self.reward_memory.data_ptr()
+        a.terminal_memory, a.batch_index = self.terminal_memory.data_ptr(), batch.data_ptr()
+        a.gamma, a.lr = self.gamma, self._lr
+        a.beta1, a.beta2, a.eps = self._betas[0], self._betas[1], self._adam_eps
+        a.loss_out = self._fused_loss.data_ptr()
+        return a
+
+    def _learn_fused(self, max_mem):
+        """sampling in PyTorch (one or two kernels), everything else in rr_dqn_update's two launches"""
+        from . import _lib
+        batch = self._sample(max_mem).contiguous()
+        args = self._fused_args(batch)
+        _lib.check(self._rrlib.rr_dqn_update(self._fused_h, C.byref(args), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                   "rr_dqn_update")
+        self._keep = batch  # the launch reads it asynchronously
+        return self._fused_loss[0]
+
+    def fused_grads(self, batch):
+        """gradient of the loss on the given replay rows as rr_dqn_grads computes it, as a dict keyed like Q_eval's parameters"""
+        from . import _lib
+        n = self._rrlib.rr_dqn_param_count()
+        flat = torch.empty(n, device=self.device)
+        args = self._fused_args(batch.contiguous())
+        _lib.check(self._rrlib.rr_dqn_grads(self._fused_h, C.byref(args), C.c_void_p(flat.data_ptr()),
+                                            C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "rr_dqn_grads")
+        torch.cuda.current_stream(self.device).synchronize()
+        names = ["fc2.weight", "fc1.weight", "fc3.weight", "fc1.bias", "fc2.bias", "fc3.bias"]  # the handle's flat order
+        shapes = dict(self.Q_eval.named_parameters())
+        out, off = {}, 0
+        for nm in names:
+            k = shapes[nm].numel()
+            out[nm] = flat[off:off + k].view_as(shapes[nm]).clone()
+            off += k
+        return out, float(self._fused_loss[0])
 
     def _learn_core(self, max_mem):
         """sampling + TD target + one Adam step (Training_DQN_pytorch.py:156-186); everything on the device, no host sync"""
@@ -210,9 +272,13 @@ class BatchedDQNAgent:
         if self.mem_cntr < self.batch_size:
             return None
         max_mem = min(self.mem_size, self.mem_cntr)
-        if self.use_graph and self.device.type == "cuda" and max_mem == self.mem_size and not getattr(self, "_graph_tried", False):
+        if self.fused:
+            loss = self._learn_fused(max_mem)
+        elif self.use_graph and self.device.type == "cuda" and max_mem == self.mem_size and not getattr(self, "_graph_tried", False):
             self._try_capture(max_mem)
-        if getattr(self, "_graph", None) is not None and self._graph_mem == max_mem:
+        if self.fused:
+            pass
+        elif getattr(self, "_graph", None) is not None and self._graph_mem == max_mem:
             self._graph.replay()
             loss = self._graph_loss
         else:
@@ -235,15 +301,36 @@ class BatchedDQNAgent:
         return self.last_loss
 
     # whole-agent checkpoint like the reference's pickle (Training_DQN_pytorch.py:373-376), without the replay
+    def _fused_adam(self, state=None):
+        """the fused step's Adam moments + step count out of (state=None) or into the handle"""
+        from . import _lib
+        n = self._rrlib.rr_dqn_param_count()
+        if state is None:
+            m1, m2 = torch.empty(n, device=self.device), torch.empty(n, device=self.device)
+            step = C.c_int64(0)
+        else:
+            m1, m2 = state["exp_avg"].to(self.device).contiguous(), state["exp_avg_sq"].to(self.device).contiguous()
+            step = C.c_int64(int(state["step"]))
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._rrlib.rr_dqn_adam_state(self._fused_h, C.c_void_p(m1.data_ptr()), C.c_void_p(m2.data_ptr()), C.byref(step),
+                                                 0 if state is None else 1, st), "rr_dqn_adam_state")
+        torch.cuda.current_stream(self.device).synchronize()
+        return dict(exp_avg=m1, exp_avg_sq=m2, step=step.value)
+
     def state_dict(self):
-        return dict(q_eval=self.Q_eval.state_dict(), q_target=self.Q_target.state_dict(),
-                    optimizer=self.Q_eval.optimizer.state_dict(), epsilon=self.epsilon, mem_cntr=self.mem_cntr,
-                    next_target_sync=self._next_target_sync, updates=self.updates, target_syncs=self.target_syncs)
+        sd = dict(q_eval=self.Q_eval.state_dict(), q_target=self.Q_target.state_dict(),
+                  optimizer=self.Q_eval.optimizer.state_dict(), epsilon=self.epsilon, mem_cntr=self.mem_cntr,
+                  next_target_sync=self._next_target_sync, updates=self.updates, target_syncs=self.target_syncs)
+        if self.fused:
+            sd["fused_adam"] = self._fused_adam()
+        return sd
 
     def load_state_dict(self, sd, lr_override=0.0, epsilon_override=0.0, eps_dec_override=0.0):
         self.Q_eval.load_state_dict(sd["q_eval"])
         self.Q_target.load_state_dict(sd["q_target"])
         self.Q_eval.optimizer.load_state_dict(sd["optimizer"])
+        if self.fused and "fused_adam" in sd:
+            self._fused_adam(sd["fused_adam"])
         self.epsilon = sd["epsilon"]
         self.updates, self.target_syncs = sd.get("updates", 0), sd.get("target_syncs", 0)
         # The replay memory is not checkpointed (the reference pickles it with the agent), so the transition counter
@@ -252,6 +339,7 @@ class BatchedDQNAgent:
         self._eps_cntr = self.mem_cntr
         self._next_target_sync = (self.mem_cntr // self.target_update_freq + 1) * self.target_update_freq
         if lr_override > 0:  # Training_DQN_pytorch.py:297-303
+            self._lr = lr_override
             for g in self.Q_eval.optimizer.param_groups:
                 g["lr"] = lr_override
         if epsilon_override > 0:
@@ -277,7 +365,7 @@ def evaluate(env, policy, episodes=1):
 def train(num_envs=65536, steps=300, preset="T", device="cuda:0", seed=0, checkpoint=None, resume=None,
           log_every=50, learn=True, mem_size=None, dtype="f64", updates_per_step=4, batch_size=None,
           replay_vector_steps=32, target_sync_vector_steps=64, eps_dec=.999997, eps_end=0.2, eval_every=0,
-          eval_envs=16384, out=None, overlap_learn=True):
+          eval_envs=16384, out=None, overlap_learn=True, step_budget_clocks=0, fused=None):
     """The main loop of Training_DQN_pytorch.py:317-377 over a batched env.  Returns a dict of throughput / score /
     the return curve (greedy policy vs the random policy on a separate evaluation batch, every `eval_every` steps).
 
@@ -287,7 +375,10 @@ def train(num_envs=65536, steps=300, preset="T", device="cuda:0", seed=0, checkp
     store_transition(t) waits for the side stream -> choose_action(t+1).  The updates see the replay one vector step later
     than in the serial order (same number of updates, same schedules)."""
     import roborugby_amd as rr
-    env = rr.make("RoboRugbySimpleDuel-v3", num_envs=num_envs, preset=preset, device=device, seed=seed, dtype=dtype)
+    # step_budget_clocks > 0: the budgeted step (include/roborugby_amd.h) -- an arena whose step is still in progress reports
+    # NOT_READY; its row is no transition yet, and the transition it completes later carries the action it ACCEPTED
+    env = rr.make("RoboRugbySimpleDuel-v3", num_envs=num_envs, preset=preset, device=device, seed=seed, dtype=dtype,
+                  step_budget_clocks=step_budget_clocks)
     p = env.preset
     if p.game_mode:  # Training_DQN_pytorch.py:233-234
         raise Exception("Game mode settings are enabled in RR_Constants.")
@@ -296,7 +387,7 @@ def train(num_envs=65536, steps=300, preset="T", device="cuda:0", seed=0, checkp
     agent = BatchedDQNAgent(input_dims=env.observation_space.shape[0], batch_size=B, n_actions=env.action_space.n, device=device,
                             seed=seed, max_mem_size=mem_size or max(500000, replay_vector_steps * num_envs * n_teams),
                             target_update_freq=max(100000, target_sync_vector_steps * num_envs * n_teams),
-                            eps_dec=eps_dec, eps_end=eps_end)
+                            eps_dec=eps_dec, eps_end=eps_end, fused=fused)
     if resume:
         ck = torch.load(resume, map_location=device)
         agent.load_state_dict(ck["agent"])
@@ -323,11 +414,16 @@ def train(num_envs=65536, steps=300, preset="T", device="cuda:0", seed=0, checkp
     overlap = bool(overlap_learn and learn and torch.device(device).type == "cuda")
     main_stream = torch.cuda.current_stream(torch.device(device))
     side = torch.cuda.Stream(device=torch.device(device)) if overlap else None
+    parked = None  # budgeted step: arenas whose step was still in progress after the last call
     for i in range(steps):
         action = agent.choose_action(observation)
-        acts = action.view(-1, 1)
         if grumpy:
             action_grumpy = agent.choose_action(obs_grumpy)
+        if parked is not None:  # a parked arena ignores the new action: the transition it will complete belongs to the one it accepted
+            action = torch.where(parked, accepted, action)
+            if grumpy:
+                action_grumpy = torch.where(parked, accepted_g, action_grumpy)
+        acts = action.view(-1, 1)
         learned = None
         if overlap:  # the gradient steps on what the replay holds so far, next to the simulator's step
             chosen = torch.cuda.Event()
@@ -339,7 +435,11 @@ def train(num_envs=65536, steps=300, preset="T", device="cuda:0", seed=0, checkp
                 learned = torch.cuda.Event()
                 learned.record(side)
         observation_, reward, done, info = env.step(acts)
-        real = (info.status & 1024) == 0  # a call that only re-placed the arena is not a transition
+        real = (info.status & (1024 | 16384)) == 0  # a call that only re-placed the arena, or left its step unfinished, is not a transition
+        if step_budget_clocks:
+            parked, accepted = (info.status & 16384) != 0, action
+            if grumpy:
+                accepted_g = action_grumpy
         score_sum += reward
         if learn:
             if learned is not None:
@@ -379,7 +479,7 @@ def train(num_envs=65536, steps=300, preset="T", device="cuda:0", seed=0, checkp
                learn_calls=agent.updates, updates_per_step=updates_per_step if learn else 0, batch_size=B,
                samples_per_transition=(updates_per_step * B / (num_envs * n_teams)) if learn else 0.0, overlap_learn=overlap,
                replay_transitions=agent.mem_size, target_update_freq=agent.target_update_freq, target_syncs=agent.target_syncs,
-               epsilon=agent.epsilon, eps_dec=eps_dec, eps_end=eps_end, finished_episodes=int(cnt.sum()),
+               epsilon=agent.epsilon, eps_dec=eps_dec, eps_end=eps_end, finished_episodes=int(cnt.sum()), fused_learn_step=bool(agent.fused),
                mean_step_reward=float(score_sum.mean() / steps), preset=preset, dtype=dtype, curve=curve)
     if eval_every:
         # throughput of the rollout alone under the policy training converged to (greedy, contact-seeking), next to the random policy's
@@ -419,10 +519,13 @@ def main():
     ap.add_argument("--log-every", type=int, default=50)
     ap.add_argument("--out", default=None)
     ap.add_argument("--no-overlap", action="store_true", help="gradient steps after the simulator's step instead of next to it")
+    ap.add_argument("--no-fused", action="store_true", help="learn step through PyTorch autograd + torch.optim.Adam instead of rr_dqn_update")
+    ap.add_argument("--budget", type=int, default=0, help="step_budget_clocks of the env (the budgeted step; 0 = synchronous)")
     a = ap.parse_args()
     res = train(a.num_envs, a.steps, a.preset, a.device, a.seed, a.checkpoint, a.resume, learn=not a.no_learn,
                 updates_per_step=a.updates_per_step, batch_size=a.batch_size, eps_dec=a.eps_dec, eval_every=a.eval_every,
-                eval_envs=a.eval_envs, log_every=a.log_every, out=a.out, overlap_learn=not a.no_overlap)
+                eval_envs=a.eval_envs, log_every=a.log_every, out=a.out, overlap_learn=not a.no_overlap,
+                step_budget_clocks=a.budget, fused=False if a.no_fused else None)
     print(json.dumps({k: v for k, v in res.items() if k != "curve"}))
 
 

@@ -6,5 +6,5 @@ NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $ROOT/roborugby_amd/variants
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -fPIC -shared -DRR_CFG_SUBSET=${RR_SUBSET:-1} "$@" \
-  -o $ROOT/roborugby_amd/variants/lib_$NAME.so $ROOT/roborugby_amd/csrc/rr_kernels.hip
+  -o $ROOT/roborugby_amd/variants/lib_$NAME.so $ROOT/roborugby_amd/csrc/rr_kernels.hip $ROOT/roborugby_amd/csrc/rr_dqn.hip
 echo built lib_$NAME.so
