@@ -234,6 +234,19 @@ int rr_dqn_update(rr_dqn *dqn, const rr_dqn_args *args, void *stream);
  * fc2.bias, fc3.bias (the parity tests' window). */
 int rr_dqn_grads(rr_dqn *dqn, const rr_dqn_args *args, float *grads, void *stream);
 int32_t rr_dqn_param_count(void);
+/* DQNAgent.choose_action (Training_DQN_pytorch.py:138-149) for n observations (a multiple of 64) in one launch: actions[i] =
+ * argmax_a Q(obs[i]) (first maximum), or with probability epsilon a uniform action -- the draw is a function of (seed, i, call),
+ * so pass a fresh `call` counter every time.  params = the six tensors of the network to act with (rr_dqn_args.eval_params
+ * order); qvalues [n,8] is optional (NULL: not written). */
+int rr_dqn_act(rr_dqn *dqn, const float *const params[6], const float *obs, int32_t n, float epsilon, uint64_t seed, uint32_t call,
+               int32_t *actions, float *qvalues, void *stream);
+/* DQNAgent.store_transition (Training_DQN_pytorch.py:126-136) for n transitions in one launch: the rows whose `valid` byte is set
+ * (NULL: all) are appended to the replay ring at mem_cntr, mem_cntr + 1, ... (mod mem_size) in row order; count_out (device int32,
+ * nullable) receives how many.  state / new_state [n,11] f32, action [n] i32, reward [n] f32, done [n] u8 (torch.bool). */
+int rr_dqn_store(rr_dqn *dqn, const float *state, const int32_t *action, const float *reward, const float *new_state,
+                 const uint8_t *done, const uint8_t *valid, int32_t n, int64_t mem_cntr, int64_t mem_size, float *state_memory,
+                 float *new_state_memory, int64_t *action_memory, float *reward_memory, uint8_t *terminal_memory,
+                 int32_t *count_out, void *stream);
 /* Adam moments (same order as rr_dqn_grads) and step count out of / into the handle: checkpoint / resume. */
 int rr_dqn_adam_state(rr_dqn *dqn, float *exp_avg, float *exp_avg_sq, int64_t *step, int32_t set, void *stream);
 

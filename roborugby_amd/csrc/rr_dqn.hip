@@ -286,6 +286,99 @@ __global__ __launch_bounds__(NT, 1) void k_dqn_fwd_bwd(Net ev, Net tg, Batch bt,
     }
 }
 
+// DQNAgent.choose_action (Training_DQN_pytorch.py:138-149) for a whole batch of observations in ONE launch: the same tiled forward
+// as the learn step, argmax over the eight Q values (first maximum, like torch.argmax), and the epsilon-greedy draw from a
+// counter-based generator keyed by (seed, row, call counter).
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__global__ __launch_bounds__(NT, 1) void k_dqn_act(Net ev, const float *obs, int n, float epsilon, uint64_t seed, uint32_t call,
+                                                   int32_t *actions, float *qvalues) {
+    __shared__ float X0[H * LDX], X1[H * LDX], S[12 * LDX], Q[NA * TM];
+    const int t = threadIdx.x, w = t >> 6, l = t & 63, half = l >> 5, c = l & 31;
+    const int ntiles = n / TM;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        for (int e = t; e < TM * IN; e += NT) {
+            const int m = e / IN, ci = e - m * IN;
+            S[ci * LDX + m] = obs[(size_t)(tile * TM + m) * IN + ci];
+        }
+        if (t < TM) S[11 * LDX + t] = 0.0f;
+        __syncthreads();
+        forward_tile(ev, S, X0, X1, Q, w, half, c, l);
+        if (t < TM) {
+            const int row = tile * TM + t;
+            int best = 0;
+            float mx = Q[t];
+#pragma unroll
+            for (int a = 1; a < NA; a++) { const float q = Q[a * TM + t]; if (q > mx) { mx = q; best = a; } }
+            if (epsilon > 0.0f) {
+                uint32_t r[4] = { (uint32_t)row, call, 0x0AC7u, 0u };
+                philox4x32_10(r, (uint32_t)seed, (uint32_t)(seed >> 32));
+                if ((float)r[0] * 2.3283064365386963e-10f <= epsilon) best = (int)(r[1] & 7u); // np.random.random() <= epsilon: explore
+            }
+            actions[row] = best;
+            if (qvalues) {
+#pragma unroll
+                for (int a = 0; a < NA; a++) qvalues[(size_t)row * NA + a] = Q[a * TM + t];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// DQNAgent.store_transition (Training_DQN_pytorch.py:126-136) for N transitions at once: the rows whose `valid` byte is set are
+// appended to the ring in row order.  Stable compaction in two launches: k_dqn_store_scan (one workgroup) counts the valid rows of
+// every 64-row chunk and scans the counts; k_dqn_store_write gives a chunk to a wavefront -- a row's rank inside its chunk is a
+// ballot + popcount -- and every lane writes its own row.
+constexpr int STORE_THREADS = 1024;
+__global__ __launch_bounds__(STORE_THREADS) void k_dqn_store_scan(const uint8_t *valid, int n, uint32_t *chunk_off, int32_t *count_out) {
+    __shared__ uint32_t scan[STORE_THREADS];
+    const int t = threadIdx.x;
+    const int nchunks = (n + 63) / 64;
+    const int per = (nchunks + STORE_THREADS - 1) / STORE_THREADS;
+    const int lo = t * per < nchunks ? t * per : nchunks, hi = lo + per < nchunks ? lo + per : nchunks;
+    uint32_t cnt = 0;
+    for (int ch = lo; ch < hi; ch++) {
+        uint32_t c = 0;
+        const int r0 = ch * 64, r1 = r0 + 64 < n ? r0 + 64 : n;
+        if (valid) { for (int i = r0; i < r1; i++) c += valid[i] ? 1u : 0u; } else c = (uint32_t)(r1 - r0);
+        chunk_off[ch] = c; // (count for now; turned into the exclusive prefix below)
+        cnt += c;
+    }
+    scan[t] = cnt;
+    __syncthreads();
+    for (int off = 1; off < STORE_THREADS; off <<= 1) {
+        const uint32_t add = t >= off ? scan[t - off] : 0u;
+        __syncthreads();
+        scan[t] += add;
+        __syncthreads();
+    }
+    uint32_t run = scan[t] - cnt;
+    for (int ch = lo; ch < hi; ch++) { const uint32_t c = chunk_off[ch]; chunk_off[ch] = run; run += c; }
+    if (t == STORE_THREADS - 1 && count_out) *count_out = (int32_t)scan[t];
+}
+__global__ __launch_bounds__(256) void k_dqn_store_write(const float *s, const int32_t *a, const float *r, const float *s2, const uint8_t *done,
+                                                         const uint8_t *valid, int n, const uint32_t *chunk_off, int64_t mem_cntr,
+                                                         int64_t mem_size, float *sm, float *nsm, int64_t *am, float *rm, uint8_t *tm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x; // blockDim is a multiple of 64 and chunks are 64 rows: a wavefront = a chunk
+    const bool ok = i < n && (!valid || valid[i]);
+    const uint64_t m = __ballot(ok);
+    if (!ok) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const int64_t q = (mem_cntr + (int64_t)chunk_off[i >> 6] + (int64_t)rank) % mem_size;
+#pragma unroll
+    for (int k = 0; k < IN; k++) { sm[q * IN + k] = s[(size_t)i * IN + k]; nsm[q * IN + k] = s2[(size_t)i * IN + k]; }
+    am[q] = (int64_t)a[i];
+    rm[q] = r[i];
+    tm[q] = done[i] ? 1 : 0;
+}
+
 struct Params { float *w1, *b1, *w2, *b2, *w3, *b3; };
 __device__ __forceinline__ float *param_at(const Params &p, int i) {
     if (i < OFF_W1) return p.w2 + (i - OFF_W2);
@@ -302,8 +395,16 @@ __global__ void k_dqn_reduce_adam(const float *partials, int nwg, Params p, floa
                                   float eps, float bc1, float sqrt_bc2, int apply, float *grads_out, float *loss_out, int batch) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > P_COUNT) return;
-    double gd = 0.0; // (the per-workgroup partials are fp32 sums over 128 samples; their sum is taken in fp64 and rounded once)
-    for (int wg = 0; wg < nwg; wg++) gd += (double)partials[(size_t)wg * P_STRIDE + i];
+    // (the per-workgroup partials are fp32 sums over 128 samples; their sum is taken in fp64 and rounded once.  Eight independent
+    // chains: a thread's 256 loads are 284 KB apart -- one dependent chain would pay the memory latency 256 times)
+    double acc8[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    int wg = 0;
+    for (; wg + 8 <= nwg; wg += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc8[q] += (double)partials[(size_t)(wg + q) * P_STRIDE + i];
+    }
+    for (; wg < nwg; wg++) acc8[0] += (double)partials[(size_t)wg * P_STRIDE + i];
+    const double gd = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
     const float g = (float)gd;
     if (i == P_COUNT) { if (loss_out) *loss_out = (float)(gd / (double)batch); return; }
     if (grads_out) grads_out[i] = g;
@@ -325,6 +426,8 @@ struct rr_dqn {
     int device, nwg;
     float *partials, *m1, *m2;
     long long step;
+    uint32_t *chunk_off; // rr_dqn_store's per-chunk offsets (grown on demand; a call with a larger batch than any before allocates)
+    size_t chunk_cap;
 };
 
 extern "C" {
@@ -342,6 +445,7 @@ int rr_dqn_create(int32_t device, rr_dqn **out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     rr_dqn *d = new rr_dqn();
     d->device = device; d->nwg = cus; d->step = 0; d->partials = nullptr; d->m1 = nullptr; d->m2 = nullptr;
+    d->chunk_off = nullptr; d->chunk_cap = 0;
     hipError_t e = hipMalloc((void **)&d->partials, sizeof(float) * (size_t)P_STRIDE * (size_t)d->nwg);
     if (e == hipSuccess) e = hipMalloc((void **)&d->m1, sizeof(float) * P_STRIDE);
     if (e == hipSuccess) e = hipMalloc((void **)&d->m2, sizeof(float) * P_STRIDE);
@@ -362,6 +466,7 @@ int rr_dqn_create(int32_t device, rr_dqn **out) {
 int rr_dqn_destroy(rr_dqn *d) {
     if (!d) return 0;
     (void)hipFree(d->partials); (void)hipFree(d->m1); (void)hipFree(d->m2);
+    if (d->chunk_off) (void)hipFree(d->chunk_off);
     delete d;
     return 0;
 }
@@ -404,6 +509,47 @@ int rr_dqn_update(rr_dqn *d, const rr_dqn_args *a, void *stream) { return dqn_ru
 int rr_dqn_grads(rr_dqn *d, const rr_dqn_args *a, float *grads, void *stream) {
     if (!grads) return dfail(-1, "rr_dqn_grads: null output");
     return dqn_run(d, a, 0, grads, stream);
+}
+int rr_dqn_act(rr_dqn *d, const float *const params[6], const float *obs, int32_t n, float epsilon, uint64_t seed, uint32_t call,
+               int32_t *actions, float *qvalues, void *stream) {
+    if (!d || !params || !obs || !actions) return dfail(-1, "rr_dqn_act: null argument");
+    for (int k = 0; k < 6; k++) if (!params[k]) return dfail(-1, "rr_dqn_act: null parameter pointer");
+    if (n <= 0 || n % TM) return dfail(-1, "rr_dqn_act: the number of observations must be a positive multiple of 64");
+    if (!(epsilon >= 0.0f && epsilon <= 1.0f)) return dfail(-1, "rr_dqn_act: epsilon must be in [0, 1]");
+    int prev = -1;
+    const bool sw = hipGetDevice(&prev) == hipSuccess && prev != d->device && hipSetDevice(d->device) == hipSuccess;
+    Net ev = { params[0], params[1], params[2], params[3], params[4], params[5] };
+    const int ntiles = n / TM, nwg = ntiles < d->nwg ? ntiles : d->nwg;
+    hipLaunchKernelGGL(k_dqn_act, dim3(nwg), dim3(NT), 0, (hipStream_t)stream, ev, obs, (int)n, epsilon, seed, call, actions, qvalues);
+    const hipError_t e = hipGetLastError();
+    if (sw) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return dfail(-2, hipGetErrorString(e));
+    return 0;
+}
+int rr_dqn_store(rr_dqn *d, const float *state, const int32_t *action, const float *reward, const float *new_state, const uint8_t *done,
+                 const uint8_t *valid, int32_t n, int64_t mem_cntr, int64_t mem_size, float *state_memory, float *new_state_memory,
+                 int64_t *action_memory, float *reward_memory, uint8_t *terminal_memory, int32_t *count_out, void *stream) {
+    if (!d || !state || !action || !reward || !new_state || !done || !state_memory || !new_state_memory || !action_memory || !reward_memory ||
+        !terminal_memory)
+        return dfail(-1, "rr_dqn_store: null argument");
+    if (n <= 0 || mem_size <= 0 || mem_cntr < 0 || n > mem_size) return dfail(-1, "rr_dqn_store: bad sizes");
+    int prev = -1;
+    const bool sw = hipGetDevice(&prev) == hipSuccess && prev != d->device && hipSetDevice(d->device) == hipSuccess;
+    const size_t need = ((size_t)n + 63) / 64;
+    if (need > d->chunk_cap) {
+        if (d->chunk_off) (void)hipFree(d->chunk_off);
+        d->chunk_off = nullptr; d->chunk_cap = 0;
+        if (hipMalloc((void **)&d->chunk_off, sizeof(uint32_t) * need) != hipSuccess) { if (sw) (void)hipSetDevice(prev); return dfail(-3, "rr_dqn_store: out of device memory"); }
+        d->chunk_cap = need;
+    }
+    hipLaunchKernelGGL(k_dqn_store_scan, dim3(1), dim3(STORE_THREADS), 0, (hipStream_t)stream, valid, (int)n, d->chunk_off, count_out);
+    hipLaunchKernelGGL(k_dqn_store_write, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, state, action, reward, new_state, done, valid,
+                       (int)n, (const uint32_t *)d->chunk_off, mem_cntr, mem_size, state_memory, new_state_memory, action_memory, reward_memory,
+                       terminal_memory);
+    const hipError_t e = hipGetLastError();
+    if (sw) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return dfail(-2, hipGetErrorString(e));
+    return 0;
 }
 int rr_dqn_adam_state(rr_dqn *d, float *exp_avg, float *exp_avg_sq, int64_t *step, int32_t set, void *stream) {
     if (!d || !exp_avg || !exp_avg_sq || !step) return dfail(-1, "rr_dqn_adam_state: null argument");

@@ -99,6 +99,7 @@ class BatchedDQNAgent:
         self.updates = 0
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(seed)
+        self._seed = int(seed)
         torch.manual_seed(seed)
         self.Q_eval = DeepQNetwork(lr, input_dims, fc1_dims, fc2_dims, n_actions).to(self.device)
         if self.device.type == "cuda":
@@ -136,6 +137,8 @@ class BatchedDQNAgent:
         """[N,11] -> int32 [N]: epsilon-greedy per arena (Training_DQN_pytorch.py:138-149)."""
         eps = self.epsilon if epsilon_override is None else epsilon_override
         n = observation.shape[0]
+        if self.fused and n % 64 == 0 and observation.dtype == torch.float32 and observation.shape[1] == 11:
+            return self._act_fused(observation, eps)  # one launch: tiled forward on the matrix cores + argmax + epsilon draw
         greedy = self.Q_eval(observation).argmax(dim=1)
         if eps <= 0:
             return greedy.to(torch.int32)
@@ -147,6 +150,9 @@ class BatchedDQNAgent:
     def store_transition(self, state, action, reward, state_, done, valid=None):
         """Appends N transitions to the ring (Training_DQN_pytorch.py:126-136); rows with valid=False are skipped
         (the dummy transition of an arena that was only re-placed by auto-reset)."""
+        if (self.fused and state.dtype == torch.float32 and state_.dtype == torch.float32 and reward.dtype == torch.float32
+                and state.shape[0] <= self.mem_size):
+            return self._store_fused(state, action, reward, state_, done, valid)
         if valid is not None:
             idx = valid.nonzero(as_tuple=True)[0]
             state, action, reward, state_, done = state[idx], action[idx], reward[idx], state_[idx], done[idx]
@@ -161,11 +167,41 @@ class BatchedDQNAgent:
         self.terminal_memory[pos] = done.bool()
         self.mem_cntr += n
 
+    def _store_fused(self, state, action, reward, state_, done, valid):
+        """rr_dqn_store: the compaction of the valid rows and the five ring writes in one launch"""
+        from . import _lib
+        n = state.shape[0]
+        s, s2, r = state.contiguous(), state_.contiguous(), reward.contiguous()
+        a = action.to(torch.int32).contiguous()
+        d = done.to(torch.bool).contiguous()
+        v = valid.to(torch.bool).contiguous() if valid is not None else None
+        if not hasattr(self, "_store_count"):
+            self._store_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        _lib.check(self._rrlib.rr_dqn_store(self._fused_h, p(s), p(a), p(r), p(s2), p(d), p(v), n, self.mem_cntr, self.mem_size,
+                                            p(self.state_memory), p(self.new_state_memory), p(self.action_memory), p(self.reward_memory),
+                                            p(self.terminal_memory), p(self._store_count),
+                                            C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "rr_dqn_store")
+        self.mem_cntr += n if v is None else int(self._store_count.item())  # (the one host read of the call, as in the PyTorch path)
+
     def _sample(self, max_mem):
         if max_mem <= self.PERMUTE_LIMIT:
             return torch.randperm(max_mem, generator=self.gen, device=self.device)[:self.batch_size]  # replace=False
         # a multi-million-entry memory: independent draws (two of B draws coincide with probability ~B^2 / 2 max_mem per batch)
         return torch.randint(0, max_mem, (self.batch_size,), generator=self.gen, device=self.device)
+
+    def _act_fused(self, observation, eps):
+        from . import _lib
+        obs = observation.contiguous()
+        n = obs.shape[0]
+        out = torch.empty(n, dtype=torch.int32, device=self.device)
+        ptrs = (C.c_void_p * 6)(*[p.data_ptr() for p in self.Q_eval.parameters()])
+        self._act_calls = getattr(self, "_act_calls", 0) + 1
+        _lib.check(self._rrlib.rr_dqn_act(self._fused_h, C.byref(ptrs), C.c_void_p(obs.data_ptr()), n, float(min(max(eps, 0.0), 1.0)),
+                                          int(self._seed), self._act_calls & 0xFFFFFFFF, C.c_void_p(out.data_ptr()), None,
+                                          C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "rr_dqn_act")
+        self._keep_obs = obs  # read asynchronously
+        return out
 
     def _fused_args(self, batch):
         from . import _lib

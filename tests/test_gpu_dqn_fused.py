@@ -124,3 +124,46 @@ def test_fused_agent_learns_a_bandit():
     greedy = ag.choose_action(s, epsilon_override=0.0)
     assert float((greedy == 3).float().mean()) > 0.95
     assert float(ag.last_loss) < 0.05
+
+
+def test_fused_choose_action_is_the_networks_argmax_and_explores_at_rate_epsilon():
+    from roborugby_amd.dqn import BatchedDQNAgent
+    ag = BatchedDQNAgent(batch_size=4096, device="cuda:0", seed=2, max_mem_size=8192)
+    g = torch.Generator(device="cuda:0").manual_seed(8)
+    obs = torch.rand(65536, 11, generator=g, device="cuda:0") * 400.0 - 100.0
+    a = ag.choose_action(obs, epsilon_override=0.0)
+    with torch.no_grad():
+        q = ag.Q_eval(obs)
+    ref = q.argmax(dim=1)
+    agree = (a.long() == ref)
+    # a different action only where the two fp32 forwards disagree about a near-tie of the top two Q values
+    top2 = q.topk(2, dim=1)[0]
+    gap = (top2[:, 0] - top2[:, 1])
+    assert float(agree.float().mean()) > 0.9995 and float(gap[~agree].max() if (~agree).any() else 0.0) < 1e-3 * float(q.abs().max())
+    # epsilon-greedy: the explored fraction and the uniformity of the random actions
+    e = ag.choose_action(obs, epsilon_override=0.3)
+    changed = (e != a)
+    frac = float(changed.float().mean())  # 0.3 * 7/8 of the rows end up with another action
+    assert abs(frac - 0.3 * 7 / 8) < 0.01, frac
+    e2 = ag.choose_action(obs, epsilon_override=0.3)
+    assert not torch.equal(e, e2)  # a fresh call counter: fresh draws
+    hist = torch.bincount(ag.choose_action(obs, epsilon_override=1.0).long(), minlength=8).float() / obs.shape[0]
+    assert float((hist - 0.125).abs().max()) < 0.01
+
+
+def test_fused_store_transition_equals_the_pytorch_path():
+    from roborugby_amd.dqn import BatchedDQNAgent
+    a1 = BatchedDQNAgent(batch_size=4096, device="cuda:0", seed=2, max_mem_size=10_000)
+    a2 = BatchedDQNAgent(batch_size=4096, device="cuda:0", seed=2, max_mem_size=10_000, fused=False)
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    for it in range(5):  # 5 x 3,000 rows into a 10,000-row ring: wraps around, with 10 % of the rows invalid
+        n = 3000
+        s = torch.rand(n, 11, generator=g, device="cuda:0"); s2 = torch.rand(n, 11, generator=g, device="cuda:0")
+        a = torch.randint(0, 8, (n,), generator=g, device="cuda:0", dtype=torch.int32)
+        r = torch.randn(n, generator=g, device="cuda:0"); d = torch.rand(n, generator=g, device="cuda:0") < 0.1
+        v = (torch.rand(n, generator=g, device="cuda:0") < 0.9) if it % 2 else None
+        a1.store_transition(s, a, r, s2, d, valid=v)
+        a2.store_transition(s, a, r, s2, d, valid=v)
+        assert a1.mem_cntr == a2.mem_cntr
+    for name in ("state_memory", "new_state_memory", "action_memory", "reward_memory", "terminal_memory"):
+        assert torch.equal(getattr(a1, name), getattr(a2, name)), name
