@@ -328,11 +328,14 @@ def main():
                                    f"auto-reset on done, {env.lanes_per_env()} lanes per arena ({64 // env.lanes_per_env()} arena(s) per wavefront)"
                                    + (", arenas at uniformly random episode phases (pre-roll of one whole episode outside the timed region)"
                                       if stagger else ", timed right after a fresh reset")
-                                   + (f", BUDGETED step ({args.budget} clocks): {n_not_ready} NOT_READY rows not counted" if args.budget else ""),
+                                   + (f", BUDGETED step ({args.budget} clocks): {n_not_ready} NOT_READY rows not counted" if args.budget else "")
+                                   + (", fp32 FAST MODE: state and arithmetic in fp32 -- the 1e-5 parity bar holds on quiet steps only "
+                                      "(contact steps: statistical, tests/test_gpu_fp32.py); fp64 is the parity mode" if args.dtype == "f32" else ""),
                        "arenas_per_gpu": n, "preset": args.preset, "policy": args.policy, "lanes_per_arena": env.lanes_per_env(),
                        "sharding": f"dp{world} (independent arena shards, returns all-gathered every "
                                    f"{gather_every} steps and once after the loop)" if world > 1 else "single GPU",
                        "steps_per_launch": F, "fault_status_bits_seen": status_bits, "staggered_phases": bool(stagger),
+                       "parity_mode": args.dtype == "f64",
                        "step_budget_clocks": args.budget, "not_ready_fraction": n_not_ready / float(n * K),
                        "collectives": {"all_gather_calls": len(pending), "ranks": world, "backend": rrd.backend_name(),
                                        "bytes_per_rank": 4 * n, "gathered_rows": gathered_rows[-1] if gathered_rows else 0,

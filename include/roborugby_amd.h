@@ -54,7 +54,7 @@ typedef struct rr_env rr_env; /* opaque */
 typedef struct rr_config {
     int32_t struct_size;    /* = sizeof(rr_config), for forward compatibility                          */
     int32_t num_envs;       /* N arenas stepped in lockstep by this handle                             */
-    int32_t nr_happy, nr_grumpy, nb_pos, nb_neg; /* RR_Constants.py:30-34; supported: (1,0,1,0), (2,2,4,4) */
+    int32_t nr_happy, nr_grumpy, nb_pos, nb_neg; /* RR_Constants.py:30-34; built shapes: (1,0,1,0), (2,2,4,4), (1,1,1,1) */
     double arena_w, arena_h;                     /* RR_Constants.py:6-7                                */
     int32_t game_len_steps; /* RR_Constants.py:25                                                      */
     int32_t game_mode;      /* RR_Constants.py:4: only selects the undo-loop fault rule (EnvBase:417-421) */
@@ -182,6 +182,8 @@ int rr_track_prior_step(rr_env *env, int32_t on, void *stream);
  * is consumed (out of play from then on: parked at x <= -1000), +-500 points (happy team +500 for a positive ball in the happy
  * goal / a negative one in the grumpy goal, the grumpy team the opposite), 3 negative balls destroy a goal, and a destroyed goal
  * or an empty field ends the episode (done = 1, status bits below; BaseDestruction pays when it is in the keeper program).
+ * Ordering: the step that consumes a ball still OBSERVES it inside the goal (the goal bookkeeping runs after the step's
+ * observation is taken); the ball is out of play from the next observation on.
  * rr_goal_scores: Goal.get_score() of (happy, grumpy) goal per arena, int32 [N,2]; all zero while the mode is off. */
 #define RR_STATUS_GOAL_H_DESTROYED 2048
 #define RR_STATUS_GOAL_G_DESTROYED 4096

@@ -3,6 +3,9 @@
 The reference has one source-level switch, GAME_MODE (RR_Constants.py:4); both settings are first-class here:
   G  GAME_MODE=True  (as checked in): 800x800, 2+2 robots, 4+4 balls, 4500-step games   (main.py)
   T  GAME_MODE=False: 600x600, 1+0 robots, 1+0 balls, 300-step games  (required by Training_DQN_pytorch.py:233-234)
+A third compiled shape, D (the two-team "duel" the SimpleDuel* classes are named after): GAME_MODE=True with the four entity
+counts of RR_Constants.py:30-34 set to 1 -- 800x800, 1+1 robots, 1+1 balls, 4500-step games.  The reference reaches it by editing
+those four integers; its golden vectors are generated with exactly that edit (oracle/refgen/load_reference.py).
 """
 import math
 from dataclasses import dataclass
@@ -49,6 +52,7 @@ class Preset:
 PRESETS = {
     "G": Preset("G", True, 800.0, 800.0, 2, 2, 4, 4, 30, int(2.5 * 60 * 30)),
     "T": Preset("T", False, 600.0, 600.0, 1, 0, 1, 0, 30, int(10 / 60 * 60 * 30)),
+    "D": Preset("D", True, 800.0, 800.0, 1, 1, 1, 1, 30, int(2.5 * 60 * 30)),
 }
 
 ROBOT_LENGTH, ROBOT_WIDTH = 20, 40  # RR_Constants.py:8-9

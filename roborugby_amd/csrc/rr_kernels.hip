@@ -308,7 +308,7 @@ __global__ void k_policy_chase(const float *obs, int n, int na, uint32_t noise_u
 // ------------------------------------------------------------------------------------------------ host side
 struct rr_env {
     rr_config cfg;
-    int kind; // 0 T64, 1 G64, 2 T32, 3 G32
+    int kind; // shape + RR_NUM_SHAPES * (dtype == f32): 0 T64, 1 G64, 2 D64, 3 T32, 4 G32, 5 D32
     int vw;   // lanes per arena
     void *recs;
     int32_t *irecs;      // the int part of the records: recs + P_REALS (same allocation, same stride)
@@ -390,7 +390,8 @@ int rr_create(const rr_config *cfg, rr_env **out) {
     int shape;
     if (cfg->nr_happy == 1 && cfg->nr_grumpy == 0 && cfg->nb_pos == 1 && cfg->nb_neg == 0) shape = 0;
     else if (cfg->nr_happy == 2 && cfg->nr_grumpy == 2 && cfg->nb_pos == 4 && cfg->nb_neg == 4) shape = 1;
-    else return fail(-1, "rr_create: unsupported entity counts (built shapes: 1+0 robots/1+0 balls, 2+2 robots/4+4 balls)");
+    else if (cfg->nr_happy == 1 && cfg->nr_grumpy == 1 && cfg->nb_pos == 1 && cfg->nb_neg == 1) shape = 2;
+    else return fail(-1, "rr_create: unsupported entity counts (built shapes: 1+0 robots/1+0 balls, 2+2 robots/4+4 balls, 1+1 robots/1+1 balls)");
     if (cfg->dtype != RR_DTYPE_F64 && cfg->dtype != RR_DTYPE_F32) return fail(-1, "rr_create: bad dtype");
     if (!(cfg->arena_w >= 300 && cfg->arena_h >= 300 && cfg->arena_w <= 8192 && cfg->arena_h <= 8192))
         return fail(-1, "rr_create: arena size out of range [300, 8192]");
@@ -402,7 +403,7 @@ int rr_create(const rr_config *cfg, rr_env **out) {
     rr_env *e = new (std::nothrow) rr_env();
     if (!e) return fail(-3, "rr_create: out of host memory");
     e->cfg = *cfg;
-    e->kind = shape + 2 * (cfg->dtype == RR_DTYPE_F32 ? 1 : 0);
+    e->kind = shape + RR_NUM_SHAPES * (cfg->dtype == RR_DTYPE_F32 ? 1 : 0);
     e->vw = 0;
     e->prog.n = 3; e->prog.id[0] = KEEPER_NAUGHTY; e->prog.id[1] = KEEPER_CHASE; e->prog.id[2] = KEEPER_PUSHPOS;
     e->custom_prog = false; e->track_prior = false; e->xs = nullptr; e->status_buf = nullptr; e->gs = nullptr;
@@ -552,7 +553,7 @@ static int step_impl(rr_env *e, const int32_t *actions, const float *thrust, int
                 hipLaunchKernelGGL((k_step<CC, O, false>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (RR *)e->recs, e->irecs, n,
                                    actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status, (const uint32_t *)e->order, e->cost,
                                    1, 0, e->snap, e->isnap);
-            else if constexpr (std::is_same<O, float>::value && (CC::NR == 1 ? CC::VW == 2 : CC::VW == 8)) // default lane widths only (build time)
+            else if constexpr (std::is_same<O, float>::value && CC::VW == default_vw<CC>()) // default lane widths only (build time)
                 hipLaunchKernelGGL((k_step<CC, O, true>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (RR *)e->recs, e->irecs, n,
                                    actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status, (const uint32_t *)e->order, e->cost,
                                    nsteps, repeat, e->snap, e->isnap);

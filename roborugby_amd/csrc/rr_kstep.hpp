@@ -143,20 +143,27 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
 #endif
 }
 
-// Built configurations: (kind = shape + 2*dtype, entity counts, Real, VW).  The first VW listed for a kind is the
-// default; the environment variable RR_VW selects another built width (kernel tuning / A-B runs).
+// Built configurations: (kind = shape + 3*dtype, entity counts, Real, VW); shapes: 0 = T (1+0 robots, 1+0 balls), 1 = G (2+2, 4+4),
+// 2 = D (1+1 robots, 1+1 balls: the two-team duel).  The first VW listed for a kind is the default; the environment variable
+// RR_VW selects another built width (kernel tuning / A-B runs).
 #if defined(RR_CFG_SUBSET) && RR_CFG_SUBSET == 2 // occupancy probe: T at 4 lanes per arena (its LDS admits 4 waves per SIMD)
 #define RR_FOR_EACH_CFG(X) X(0, 1, 0, 1, 0, double, 4) X(1, 2, 2, 4, 4, double, 8)
+#elif defined(RR_CFG_SUBSET) && RR_CFG_SUBSET == 3 // tuning builds of the duel shape
+#define RR_FOR_EACH_CFG(X) X(2, 1, 1, 1, 1, double, 4) X(1, 2, 2, 4, 4, double, 8)
 #elif defined(RR_CFG_SUBSET) // tuning builds only (tools/build_variant.sh): the two default configurations, quick to compile
 #define RR_FOR_EACH_CFG(X) X(0, 1, 0, 1, 0, double, 2) X(1, 2, 2, 4, 4, double, 8)
 #else
 #define RR_FOR_EACH_CFG(X)                                                                             \
     X(0, 1, 0, 1, 0, double, 2) X(0, 1, 0, 1, 0, double, 4) X(0, 1, 0, 1, 0, double, 8) X(0, 1, 0, 1, 0, double, 64) \
     X(1, 2, 2, 4, 4, double, 8) X(1, 2, 2, 4, 4, double, 16) X(1, 2, 2, 4, 4, double, 32) X(1, 2, 2, 4, 4, double, 64) \
-    X(2, 1, 0, 1, 0, float, 2) X(2, 1, 0, 1, 0, float, 4) X(2, 1, 0, 1, 0, float, 64)                                 \
-    X(3, 2, 2, 4, 4, float, 8) X(3, 2, 2, 4, 4, float, 16) X(3, 2, 2, 4, 4, float, 64)
+    X(2, 1, 1, 1, 1, double, 4) X(2, 1, 1, 1, 1, double, 8) X(2, 1, 1, 1, 1, double, 64)                              \
+    X(3, 1, 0, 1, 0, float, 2) X(3, 1, 0, 1, 0, float, 4) X(3, 1, 0, 1, 0, float, 64)                                 \
+    X(4, 2, 2, 4, 4, float, 8) X(4, 2, 2, 4, 4, float, 16) X(4, 2, 2, 4, 4, float, 64)                                \
+    X(5, 1, 1, 1, 1, float, 4)
 #endif
-
+constexpr int RR_NUM_SHAPES = 3;
+// default lanes per arena of a shape (the widths rr_rollout's multi-step variant is built for)
+template <class C> constexpr int default_vw() { return C::NR == 1 ? 2 : C::NR == 2 ? 4 : 8; }
 
 // ---- split build: the same list once more, with the translation unit (part) each configuration's k_step instantiations are
 // compiled in -- G kernels are the slow ones to compile, so they are spread first.  X(part, NRH, NRG, NBP, NBN, Real, VW, DEF)
@@ -164,10 +171,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
 #define RR_KSTEP_PARTS 7
 #define RR_FOR_EACH_CFG_F64_PARTS(X)                                                                                   \
     X(5, 1, 0, 1, 0, double, 2, 1) X(5, 1, 0, 1, 0, double, 4, 0) X(6, 1, 0, 1, 0, double, 8, 0) X(6, 1, 0, 1, 0, double, 64, 0) \
-    X(0, 2, 2, 4, 4, double, 8, 1) X(1, 2, 2, 4, 4, double, 16, 0) X(2, 2, 2, 4, 4, double, 32, 0) X(3, 2, 2, 4, 4, double, 64, 0)
+    X(0, 2, 2, 4, 4, double, 8, 1) X(1, 2, 2, 4, 4, double, 16, 0) X(2, 2, 2, 4, 4, double, 32, 0) X(3, 2, 2, 4, 4, double, 64, 0) \
+    X(1, 1, 1, 1, 1, double, 4, 1) X(2, 1, 1, 1, 1, double, 8, 0) X(3, 1, 1, 1, 1, double, 64, 0)
 #define RR_FOR_EACH_CFG_F32_PARTS(X)                                                                                   \
     X(6, 1, 0, 1, 0, float, 2, 1) X(6, 1, 0, 1, 0, float, 4, 0) X(6, 1, 0, 1, 0, float, 64, 0)                         \
-    X(4, 2, 2, 4, 4, float, 8, 1) X(4, 2, 2, 4, 4, float, 16, 0) X(5, 2, 2, 4, 4, float, 64, 0)
+    X(4, 2, 2, 4, 4, float, 8, 1) X(4, 2, 2, 4, 4, float, 16, 0) X(5, 2, 2, 4, 4, float, 64, 0)                        \
+    X(0, 1, 1, 1, 1, float, 4, 1)
 
 #define RR_KSTEP_SIG(C_, O_)                                                                                                       \
     (SimParams<typename C_::Real>, typename C_::Real *, int32_t *, int, const int32_t *, const float *, int, O_ *, O_ *, uint8_t *, \

@@ -2506,7 +2506,9 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     constexpr int ST_FATAL = ST_BOT_RESOLVE_FAIL | ST_BOT_STUCK | ST_UNDO_MOVE_FAIL | ST_UNDO_FAIL | ST_SAME_SPOT | ST_DIV0;
     const bool faulted = sp.reset_on_fault && (st & ST_FATAL); // the reference raised (or hangs) inside this step
     const bool done = is_done<R>(step_now, sp) || faulted;
-    if constexpr (C::NRH > 0 && C::NRG > 0) {
+    // (the one-pass two-team observation parks the second team's lidar candidates in per-sub-step ball scratch: it needs the room)
+    constexpr bool BOTH = C::NRH > 0 && C::NRG > 0 && 6 * C::NR <= 4 * C::NB && 6 <= C::NB;
+    if constexpr (BOTH) {
         if (o.obs_g()) observe_both<C, O>(A, sp, o.obs(), o.obs_g(), st);
         else observe<C, O>(A, sp, 1, -1, -1, o.obs(), st);
     } else {

@@ -87,6 +87,10 @@ typedef Cfg<2, 2, 4, 4, float, 64> CG32;
 // narrow virtual waves: the same phases run in several rounds of VW lanes (what the packed GPU builds execute)
 typedef Cfg<1, 0, 1, 0, double, 4> CT64n;
 typedef Cfg<2, 2, 4, 4, double, 16> CG64n;
+// the duel shape (1+1 robots, 1+1 balls)
+typedef Cfg<1, 1, 1, 1, double, 64> CD64;
+typedef Cfg<1, 1, 1, 1, float, 64> CD32;
+typedef Cfg<1, 1, 1, 1, double, 4> CD64n;
 
 struct Handle { int kind; void *p; };
 
@@ -98,6 +102,9 @@ struct Handle { int kind; void *p; };
     case 3: { auto *e = (Emu<CG32> *)(h)->p; typedef CG32 CC; __VA_ARGS__; } break; \
     case 4: { auto *e = (Emu<CT64n> *)(h)->p; typedef CT64n CC; __VA_ARGS__; } break; \
     case 5: { auto *e = (Emu<CG64n> *)(h)->p; typedef CG64n CC; __VA_ARGS__; } break; \
+    case 6: { auto *e = (Emu<CD64> *)(h)->p; typedef CD64 CC; __VA_ARGS__; } break; \
+    case 7: { auto *e = (Emu<CD32> *)(h)->p; typedef CD32 CC; __VA_ARGS__; } break; \
+    case 8: { auto *e = (Emu<CD64n> *)(h)->p; typedef CD64n CC; __VA_ARGS__; } break; \
     }
 
 extern "C" {
@@ -112,12 +119,15 @@ void emu_debug_scrub(int on) { g_dbg_scrub = on; }
 // primitives of the kernel source, for unit tests
 double emu_py_mod360(double a) { return py_mod<double>(a, 360.0); }
 void emu_sincos(double x, double *s, double *c) { m_sincos(x, *s, *c); }
-// preset: 0 = T, 1 = G ; f32: 0/1 ; f32 == 2 selects the narrow-virtual-wave fp64 build
+// preset: 0 = T, 1 = G, 2 = D ; f32: 0/1 ; f32 == 2 selects the narrow-virtual-wave fp64 build
 Handle *emu_create(int preset, int f32, double W, double H, int game_len, int game_mode, int time_limit, int auto_reset,
                    uint64_t seed) {
     Handle *h = new Handle;
-    h->kind = preset + 2 * f32;
+    h->kind = preset == 2 ? 6 + f32 : preset + 2 * f32;
     switch (h->kind) {
+    case 6: h->p = calloc(1, sizeof(Emu<CD64>)); break;
+    case 7: h->p = calloc(1, sizeof(Emu<CD32>)); break;
+    case 8: h->p = calloc(1, sizeof(Emu<CD64n>)); break;
     case 0: h->p = calloc(1, sizeof(Emu<CT64>)); break;
     case 1: h->p = calloc(1, sizeof(Emu<CG64>)); break;
     case 2: h->p = calloc(1, sizeof(Emu<CT32>)); break;

@@ -16,7 +16,7 @@ def _diff(st, ref_r, ref_b):
     return max(float(np.nanmax(np.abs(st["robots"] - ref_r))), float(np.abs(st["balls"] - ref_b).max()))
 
 
-@pytest.mark.parametrize("preset,stride,narrow", [("T", 3, False), ("G", 4, False), ("T", 4, True), ("G", 5, True)])
+@pytest.mark.parametrize("preset,stride,narrow", [("T", 3, False), ("G", 4, False), ("T", 4, True), ("G", 5, True), ("D", 3, False), ("D", 4, True)])
 def test_emulated_kernel_vs_reference_golden(golden_dir, preset, stride, narrow):
     """narrow=True runs the phases with VW = 4 (T) / 16 (G) lanes per arena, i.e. in several rounds -- the
     lane->task maps of the packed GPU builds (several arenas per wavefront)."""
@@ -68,7 +68,7 @@ def test_emulated_kernel_thrust_entry_vs_reference_golden(golden_dir, preset):
     print(f"[{preset}] {n} golden thrust steps through the emulated wave, worst {worst:.2e}")
 
 
-@pytest.mark.parametrize("preset", ["T", "G"])
+@pytest.mark.parametrize("preset", ["T", "G", "D"])
 def test_emulated_reset_equals_oracle_reset(preset):
     for arena in (0, 5, 123456789):
         e, o = el.EmuEnv(preset, seed=42), ol.OracleEnv(preset)
@@ -139,7 +139,7 @@ def test_time_limit_and_auto_reset_semantics():
     assert r["status"] & 64 and r["done"]  # "Game is over. Go home." (RR_EnvBase.py:261-262)
 
 
-@pytest.mark.parametrize("preset,stride", [("T", 2), ("G", 3)])
+@pytest.mark.parametrize("preset,stride", [("T", 2), ("G", 3), ("D", 3)])
 def test_f32_mode_single_step_vs_reference_golden(golden_dir, preset, stride):
     """fp32 fast mode, one step from synchronised state on the reference's golden steps, scored like the GPU test
     (tests/fp32_checks.py, tests/test_gpu_fp32.py): quiet steps within 1e-5 relative with integer state exact, contact

@@ -31,8 +31,10 @@ def test_T_batch_of_balls_in_and_around_the_goals_matches_the_oracle():
     acts = torch.full((n, 1), 8, dtype=torch.int32, device="cuda")  # nobody moves
     total = torch.zeros(n, dtype=torch.float64, device="cuda")
     done_at = torch.full((n,), -1, dtype=torch.int64, device="cuda")
+    obs_hist = []
     for s in range(steps):
         o, r, d, info = env.step_f64(acts)
+        obs_hist.append(o.cpu().numpy())
         total += r
         done_at = torch.where((done_at < 0) & d, torch.full_like(done_at, s + 1), done_at)
     scores = env.goal_scores().cpu().numpy()
@@ -47,6 +49,8 @@ def test_T_batch_of_balls_in_and_around_the_goals_matches_the_oracle():
             res = orc.step([8])
             if res["status"] & 64:
                 break
+            # the observation too: the step that consumes the ball still sees it inside the goal, on both sides
+            assert np.abs(res["obs"] - obs_hist[s][a]).max() < 1e-9, (a, s)
             tot += res["reward"]
             if res["done"] and when < 0:
                 when = s + 1

@@ -18,7 +18,7 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-@pytest.mark.parametrize("preset", ["T", "G"])
+@pytest.mark.parametrize("preset", ["T", "G", "D"])
 def test_line_intersection_and_within(golden_dir, preset):
     k = _load(golden_dir, preset)
     L = ol.lib()
@@ -54,7 +54,7 @@ def test_floatrect_rotation_corners_copy(golden_dir, preset):
         assert np.array_equal(c7, cp), (i, inp, c7 - cp)
 
 
-@pytest.mark.parametrize("preset", ["T", "G"])
+@pytest.mark.parametrize("preset", ["T", "G", "D"])
 def test_two_way_lidar(golden_dir, preset):
     k = _load(golden_dir, preset)
     L = ol.lib()
@@ -78,7 +78,7 @@ def test_collision_predicates(golden_dir, preset):
     assert 0.15 < k["rrc_out"].mean() < 0.85
 
 
-@pytest.mark.parametrize("preset", ["T", "G"])
+@pytest.mark.parametrize("preset", ["T", "G", "D"])
 def test_constants(golden_dir, preset):
     k = _load(golden_dir, preset)
     c = k["consts"]

@@ -66,7 +66,7 @@ def _drive(env, t, ep, s):
     return env.step(acts[acts >= 0])
 
 
-@pytest.mark.parametrize("preset", ["T", "G"])
+@pytest.mark.parametrize("preset", ["T", "G", "D"])
 def test_trajectories_bit_exact(golden_dir, preset):
     t = np.load(f"{golden_dir}/traj_{preset}.npz")
     total = 0
@@ -97,7 +97,7 @@ def test_thrust_entry_bit_exact(golden_dir, preset):
     assert cov["apply_force_to_ball"] > 0 and cov["bounce_ball_off_bot"] > 0 and cov["bounce_ball_off_wall"] > 0
 
 
-@pytest.mark.parametrize("preset", ["T", "G"])
+@pytest.mark.parametrize("preset", ["T", "G", "D"])
 def test_done_flag_is_step_counter(golden_dir, preset):
     """done = lngStepCount > GAME_LENGTH_STEPS (RR_EnvBase.py:555-559); stepping after done is flagged."""
     cfg = ol.PRESETS[preset]
