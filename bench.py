@@ -230,6 +230,22 @@ def main():
         return env.step(a, out=out if o is None else o)
 
     stagger = not args.no_stagger and args.fuse == 1
+    from_reset = None
+    if stagger and args.policy == "random" and not args.budget and K + W < p.game_len_steps:
+        # secondary number, same run: the K steps right after a fresh reset (what rounds 1-2 reported as the headline: every
+        # arena at the same, contact-poor start of its episode) -- kept so that the lines stay comparable across rounds
+        for i in range(W):
+            env.step(acts[i], out=out)
+        rrd.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(K):
+            env.step(acts[W + i], out=out)
+        torch.cuda.synchronize()
+        rrd.barrier()
+        dt0 = rrd.reduce_max(time.perf_counter() - t0, dev)
+        from_reset = {"value": rrd.reduce_sum(float(n * K), dev) / dt0, "ms_per_step": dt0 / K * 1e3,
+                      "note": f"{K} steps right after a fresh reset (steps {W + 1}..{W + K} of the episode), same process, before the pre-roll"}
     if stagger:
         # Steady state: every arena at a uniformly random phase of its episode, with the state a rollout of that length leaves
         # (contacts accumulate late in an episode: robots park balls against walls).  The step counters are spread over
@@ -349,6 +365,8 @@ def main():
                          "note": "latency/VALU-bound by construction: 12 dependent sub-steps of fp64 geometry per "
                                  "149-601 B of state; the HBM fraction is reported because BASELINE.json asks for it"},
         }
+        if from_reset is not None:
+            line["from_reset"] = from_reset
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.preset, args.cpu_seconds)
         print(json.dumps(line), flush=True)

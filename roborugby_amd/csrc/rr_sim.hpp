@@ -1311,6 +1311,33 @@ template <class C> RR_HD void ball_undo_lane(Arena<C> &A, int b) {
     A.p.bcy[b] = (R)7 + dy; A.p.bt[b] = (R)0 + dy; A.p.bb[b] = (R)14 + dy;
 }
 
+// budgeted step (see step_arena): the clock an arena is measured against, and what a sub-step that parks BETWEEN TWO PASSES of its
+// resolve loop hands back
+struct ParkCtx {
+    uint32_t *buf = nullptr;            // this arena's PARK_WORDS slot
+    uint32_t budget = 0;                // shader clocks (s_memtime ticks) a wavefront may run before its expensive arenas park
+    unsigned long long t_begin = 0;     // s_memtime at the wavefront's start
+    uint32_t *host_rng = nullptr;       // host emulation only: park at pseudo-random sub-step boundaries, quiet ones included
+    uint32_t host_mod = 0;              //   (1 in host_mod; <= 1: at every boundary)
+    RR_HD bool over(int work) const {
+#if RR_GPU
+        return work > 0 && (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin) > (unsigned long long)budget;
+#else
+        (void)work;
+        if (!host_rng) return false;
+        *host_rng = *host_rng * 1664525u + 1013904223u;
+        return host_mod <= 1 || ((*host_rng >> 16) % host_mod) == 0;
+#endif
+    }
+};
+struct MidState {
+    int phase = 0;      // 0: at a sub-step boundary; 1: inside _resolve_ball_collisions, before pass `count + 1`
+    int count = 0;
+    uint32_t bots_moved = 0, balls_moved = 0, n_sub = 0;
+    int st_sub = 0, work = 0;
+    Hit hit = { 0, 0 };
+};
+
 // ------------------------------------------------------------------------------------------------ sub-step pieces (RR_EnvBase.py:303-454)
 // returns whether any pair collided (i.e. whether any robot may have been put back)
 template <class C> RR_HDN bool resolve_bot_collisions(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &bots_moved, uint32_t &naughty, int &st, int &work, Hit &hit) {
@@ -1343,15 +1370,24 @@ template <class C> RR_HDN bool resolve_bot_collisions(Arena<C> &A, const SimPara
     }
     return true;
 }
-template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t bots_moved, int &st, int &work, Hit &hit) {
+// returns 1 (resolved), 0 (gave up after 10 passes) or, budgeted step only, -1: over the budget between two passes -- `count` passes are
+// done, the caller parks the arena and a later call re-enters here with count0 = count (at least one pass runs per entry)
+template <class C, bool BUDGET = false>
+RR_HDN int resolve_ball_collisions(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t bots_moved, int &st, int &work, Hit &hit,
+                                   int count0 = 0, const ParkCtx *pk = nullptr, int *count_out = nullptr) {
     bool naughty = true;
-    int count = 0;
+    int count = count0;
     RR_T0();
-    RR_FOR_LANES(l) { if (l < C::NB) ball_exc_update(A, l); } // where the push and the roll have left each ball
+    if (!BUDGET || count0 == 0) {
+        RR_FOR_LANES(l) { if (l < C::NB) ball_exc_update(A, l); } // where the push and the roll have left each ball
+    }
     while (naughty) {
+        if constexpr (BUDGET) {
+            if (count > count0 && count < 10 && RR_UNLIKELY(pk->over(1))) { *count_out = count; return -1; }
+        }
         count++;
         work++;
-        if (count > 10) { RR_TRACE("E resolve gave up\n"); return false; }
+        if (count > 10) { RR_TRACE("E resolve gave up\n"); return 0; }
         naughty = false;
         uint64_t bb = detect_ball_pairs(A);
 #pragma unroll 1
@@ -1387,7 +1423,7 @@ template <class C> RR_HDN bool resolve_ball_collisions(Arena<C> &A, const SimPar
         RR_STAMP(17);
     }
     RR_TRACE("E resolve done in %d passes\n", count);
-    return true;
+    return 1;
 }
 template <class C>
 RR_HDN void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &balls_moved,
@@ -1648,13 +1684,25 @@ template <class C> RR_HD void thaw_island(Arena<C> &A, const SimParams<typename 
 // after the roll phase, the push restricted to K and their roll), and the reference-shaped path runs for the whole
 // arena as if it had never been frozen.  The island's robots are never held back: they make their real move in phase 1
 // like every robot (how it meets the walls depends on their drifting edges) and are put back at the end of the sub-step.
-template <class C>
-RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &naughty, int &st, uint32_t &prev_moved,
-                   int &work, Hit &fz, Hit &hit) {
+// Budgeted step: returns true when the arena parked between two passes of the resolve loop (`mid` holds where); a call with
+// mid->phase == 1 skips everything before that loop and re-enters it.
+template <class C, bool BUDGET = false>
+RR_HD bool substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &naughty, int &st, uint32_t &prev_moved,
+                   int &work, Hit &fz, Hit &hit, MidState *mid = nullptr, const ParkCtx *pk = nullptr) {
     using R = typename C::Real;
     uint32_t bots_moved = ((1u << C::NR) - 1) & ~fz.r, balls_moved = (1u << C::NB) - 1;
     RR_TRACE("E substep\n");
     RR_T0();
+    uint64_t m_any = 0;
+    int count0 = 0;
+    bool reentry = false;
+    if constexpr (BUDGET) reentry = mid->phase == 1;
+    if (RR_UNLIKELY(reentry)) {
+        bots_moved = mid->bots_moved; balls_moved = mid->balls_moved; naughty = mid->n_sub; st = mid->st_sub; work = mid->work; hit = mid->hit;
+        count0 = mid->count;
+        mid->phase = 0;
+        m_any = 1;
+    } else {
     // phase 1: frame hooks, robot moves AND the exact broad phase.  The broad phase runs in the same phase as the moves:
     // it may see a robot centre from before or after this sub-step's move, so its bounds carry the largest centre
     // displacement a move can cause (1 px drive / 0.17 px pivot / <= 1.5 px wall clamp: 3 px per robot is generous).
@@ -1688,7 +1736,6 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     // phase 2: _roll_balls AND the fused first pass of _resolve_ball_collisions: anything possibly touching?  Ball-ball
     // runs in the same phase as the roll, so the other ball may be seen before or after its own roll: the bound (A.reach,
     // written at the frame hooks and refreshed by the push) adds the most it can travel in its roll.  Ball-robot uses the settled robot centres; the wall test is the exact int-rect test.
-    uint64_t m_any = 0;
     RR_TRACE("E phase1 rr %d br %d\n", (int)(m_rr != 0), (int)(m_br != 0));
     if (RR_UNLIKELY(frozen && (fz.r | fz.b))) substep_phase2<C, true>(A, sp, fz, m_any);
     else substep_phase2<C, false>(A, sp, fz, m_any);
@@ -1708,10 +1755,19 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
         RR_SYNC();
     }
     RR_TRACE("E phase2 any %d\n", (int)(m_any != 0));
+    } // !reentry
     if (RR_UNLIKELY(m_any)) { // the reference's loop, from its first pass (nothing has changed since the broad phase above)
-        bool rr_ok_ = resolve_ball_collisions(A, sp, bots_moved, st, work, hit);
+        int count_now = 0;
+        const int rr_ok_ = resolve_ball_collisions<C, BUDGET>(A, sp, bots_moved, st, work, hit, count0, pk, &count_now);
+        if constexpr (BUDGET) {
+            if (RR_UNLIKELY(rr_ok_ < 0)) { // over the budget between two passes: hand the loop's state back, the arena parks
+                mid->phase = 1; mid->count = count_now; mid->bots_moved = bots_moved; mid->balls_moved = balls_moved;
+                mid->n_sub = naughty; mid->st_sub = st; mid->work = work; mid->hit = hit;
+                return true;
+            }
+        }
         RR_STAMP(5);
-        if (!rr_ok_) { work += 8; undo_naughty_movement(A, sp, balls_moved, bots_moved, st, hit); }
+        if (rr_ok_ == 0) { work += 8; undo_naughty_movement(A, sp, balls_moved, bots_moved, st, hit); }
     }
     RR_STAMP(6);
     if (RR_UNLIKELY(fz.r)) { // still frozen: the island's robots made their move in phase 1; the undo they would have met puts them back
@@ -1721,6 +1777,7 @@ RR_HD void substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
         RR_SYNC();
     }
     prev_moved = bots_moved;
+    return false;
 }
 // after the last sub-step: the pose-ring bookkeeping the next sub-step would have done
 template <class C> RR_HD void substeps_end(Arena<C> &A, uint32_t prev_moved) {
@@ -2219,23 +2276,6 @@ RR_HD int32_t float_bits(float f) { int32_t v; __builtin_memcpy(&v, &f, 4); retu
 // it ACCEPTED, is the synchronous mode's bit for bit (tests/test_budgeted_step.py: emulation parking at arbitrary boundaries,
 // GPU at budgets from 1 clock up).  Whatever rewrites an arena from outside (reset, rr_set_state, rr_set_poses) clears the
 // word, and with it the parked step.
-struct ParkCtx {
-    uint32_t *buf = nullptr;            // this arena's PARK_WORDS slot
-    uint32_t budget = 0;                // shader clocks (s_memtime ticks) a wavefront may run before its expensive arenas park
-    unsigned long long t_begin = 0;     // s_memtime at the wavefront's start
-    uint32_t *host_rng = nullptr;       // host emulation only: park at pseudo-random sub-step boundaries, quiet ones included
-    uint32_t host_mod = 0;              //   (1 in host_mod; <= 1: at every boundary)
-    RR_HD bool over(int work) const {
-#if RR_GPU
-        return work > 0 && (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin) > (unsigned long long)budget;
-#else
-        (void)work;
-        if (!host_rng) return false;
-        *host_rng = *host_rng * 1664525u + 1013904223u;
-        return host_mod <= 1 || ((*host_rng >> 16) % host_mod) == 0;
-#endif
-    }
-};
 constexpr int32_t FZP_PARKED = (int32_t)0x80000000; // Arena::I::fzp while the arena is parked mid-step
 
 template <class C>

@@ -19,8 +19,8 @@ for line in out.splitlines():
         cur = {"name": name}; rows.append(cur)
     elif cur is not None: cur[k] = v
 for r in rows:
-    m = re.match(r"void (\w+)<rr::Cfg<(\d+), (\d+), (\d+), (\d+), (\w+), (\d+)>(?:, (\w+))?>", r["name"])
-    tag = r["name"][:60] if not m else "%s %s+%s/%s+%s %s VW%s out=%s" % m.groups()
+    m = re.match(r"void (\w+)<rr::Cfg<(\d+), (\d+), (\d+), (\d+), (\w+), (\d+)>(?:, (\w+))?(?:, (\w+))?(?:, (\w+))?>", r["name"])
+    tag = r["name"][:60] if not m else "%s %s+%s/%s+%s %s VW%s out=%s multi=%s budget=%s" % m.groups()
     if flt and flt not in tag: continue
-    print("%-44s vgpr %3s agpr %3s scratch %4s occ %s spillV %3s lds %6s" % (tag, r.get("VGPRs"), r.get("AGPRs"),
+    print("%-72s vgpr %3s agpr %3s scratch %4s occ %s spillV %3s lds %6s" % (tag, r.get("VGPRs"), r.get("AGPRs"),
           r.get("ScratchSize [bytes/lane]"), r.get("Occupancy [waves/SIMD]"), r.get("VGPRs Spill"), r.get("LDS Size [bytes/block]")))
