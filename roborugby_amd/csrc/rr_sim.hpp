@@ -407,7 +407,8 @@ template <class C> struct ArenaBody {
     static constexpr int SNAP_WORDS = (P_REALS + 3 * NR) * WR, ISNAP_WORDS = 2 * NR;
     // parked mid-step state of the budgeted step (its own buffer, touched only by arenas that park): PARK_INTS ints, then
     // ax, ay, arot, psx, psy [NR each], dist_sum0, exc [NB]
-    static constexpr int PARK_INTS = 10, PARK_REALS = 5 * NR + 1 + NB, PARK_WORDS = PARK_INTS + PARK_REALS * WR;
+    // (+ when it parks between two passes of a resolve loop: the loop's registers, bmass [NB], and bfx, bfy, pfx, pfy [NB each])
+    static constexpr int PARK_INTS = 20 + NB + ((20 + NB) & 1), PARK_REALS = 5 * NR + 1 + 5 * NB, PARK_WORDS = PARK_INTS + PARK_REALS * WR;
 };
 // LDS bank spreading.  The 64/VW arenas of a wavefront sit in consecutive LDS slices and their lanes touch the SAME
 // field at the same time, so the slice stride decides the banking: lane-strided accesses of one arena cover
@@ -472,15 +473,16 @@ template <typename R> RR_HD void corners_for(R rot, R hw, R hh, R cdist, R *rel)
     sincos_deg<R>((R)360 - rot, s, c);
     corners_from_sc<R>(rot, s, c, hw, hh, cdist, rel);
 }
+RR_HD double m_min(double a, double b) { return ::fmin(a, b); }
+RR_HD double m_max(double a, double b) { return ::fmax(a, b); }
+RR_HD float m_min(float a, float b) { return ::fminf(a, b); }
+RR_HD float m_max(float a, float b) { return ::fmaxf(a, b); }
 template <typename R> RR_HD void fr_edges_from_rel(FR<R> &f) { // MyUtils.py:318-322
-    R mnx = f.rel[0], mxx = f.rel[0], mny = f.rel[1], mxy = f.rel[1];
-    for (int k = 1; k < 4; k++) {
-        R x = f.rel[2 * k], y = f.rel[2 * k + 1];
-        if (x < mnx) mnx = x;
-        if (x > mxx) mxx = x;
-        if (y < mny) mny = y;
-        if (y > mxy) mxy = y;
-    }
+    // min / max of the four corner offsets as v_min / v_max (one instruction each instead of compare + two selects: G +0.4 %, T +1 %,
+    // profiles/r03/micro_ab.txt).  The same values as the reference's `if x < mn: mn = x` chain: the offsets are never NaN and never
+    // +-0 (axis-aligned poses have offsets of exactly +-10 / +-20, every other pose a nonzero renormalised product).
+    const R mnx = m_min(m_min(f.rel[0], f.rel[2]), m_min(f.rel[4], f.rel[6])), mxx = m_max(m_max(f.rel[0], f.rel[2]), m_max(f.rel[4], f.rel[6]));
+    const R mny = m_min(m_min(f.rel[1], f.rel[3]), m_min(f.rel[5], f.rel[7])), mxy = m_max(m_max(f.rel[1], f.rel[3]), m_max(f.rel[5], f.rel[7]));
     f.l = mnx + f.cx; f.r = mxx + f.cx; f.t = mny + f.cy; f.b = mxy + f.cy;
 }
 template <typename R> RR_HD void fr_set_rot(FR<R> &f, R nr, R cdist) { // robot rect: 20 x 40
@@ -2280,15 +2282,24 @@ constexpr int32_t FZP_PARKED = (int32_t)0x80000000; // Arena::I::fzp while the a
 
 template <class C>
 RR_HD void park_save(Arena<C> &A, uint32_t *buf, int f_next, uint32_t prev_moved, uint32_t naughty, int st, const Hit &fz,
-                     uint32_t fz_bits, bool snap_valid, uint32_t snap_moved, typename C::Real dist_sum0) {
+                     uint32_t fz_bits, bool snap_valid, uint32_t snap_moved, typename C::Real dist_sum0, const MidState &mid) {
     using R = typename C::Real;
     constexpr int NR = C::NR, NB = C::NB;
     int32_t *pi = reinterpret_cast<int32_t *>(buf);
     R *pr = reinterpret_cast<R *>(buf + Arena<C>::PARK_INTS);
     RR_FOR_LANES(l) {
         if (l < NR) { pr[l] = A.ax[l]; pr[NR + l] = A.ay[l]; pr[2 * NR + l] = A.arot[l]; pr[3 * NR + l] = A.psx[l]; pr[4 * NR + l] = A.psy[l]; }
-        if (l < NB) pr[5 * NR + 1 + l] = A.exc[l];
+        if (l < NB) {
+            pr[5 * NR + 1 + l] = A.exc[l];
+            if (mid.phase) { // mid-sub-step: the frame-begin picture of the balls and what the push left in them
+                R *q = pr + 5 * NR + 1 + NB;
+                q[l] = A.bfx[l]; q[NB + l] = A.bfy[l]; q[2 * NB + l] = A.pfx[l]; q[3 * NB + l] = A.pfy[l];
+                pi[20 + l] = A.bmass[l];
+            }
+        }
         if (l == 0) {
+            pi[10] = mid.phase; pi[11] = mid.count; pi[12] = (int32_t)mid.bots_moved; pi[13] = (int32_t)mid.balls_moved;
+            pi[14] = (int32_t)mid.n_sub; pi[15] = mid.st_sub; pi[16] = mid.work; pi[17] = (int32_t)mid.hit.r; pi[18] = (int32_t)mid.hit.b;
             uint32_t wmb = 0;
             for (int r = 0; r < NR; r++) wmb |= (uint32_t)(A.wm[r] & 3) << (2 * r);
             pr[5 * NR] = dist_sum0;
@@ -2301,7 +2312,7 @@ RR_HD void park_save(Arena<C> &A, uint32_t *buf, int f_next, uint32_t prev_moved
 }
 template <class C>
 RR_HD void park_load(Arena<C> &A, const uint32_t *buf, int &f_next, uint32_t &prev_moved, uint32_t &naughty, int &st, Hit &fz,
-                     uint32_t &fz_bits, int &snap_at, uint32_t &snap_moved, typename C::Real &dist_sum0) {
+                     uint32_t &fz_bits, int &snap_at, uint32_t &snap_moved, typename C::Real &dist_sum0, MidState &mid) {
     using R = typename C::Real;
     constexpr int NR = C::NR, NB = C::NB;
     static_assert(NR <= 16, "wm bytes travel as 2 bits per robot in one word");
@@ -2313,8 +2324,17 @@ RR_HD void park_load(Arena<C> &A, const uint32_t *buf, int &f_next, uint32_t &pr
             A.ax[l] = pr[l]; A.ay[l] = pr[NR + l]; A.arot[l] = pr[2 * NR + l]; A.psx[l] = pr[3 * NR + l]; A.psy[l] = pr[4 * NR + l];
             A.wm[l] = (uint8_t)((wmb >> (2 * l)) & 3u);
         }
-        if (l < NB) A.exc[l] = pr[5 * NR + 1 + l];
+        if (l < NB) {
+            A.exc[l] = pr[5 * NR + 1 + l];
+            if (pi[10]) {
+                const R *q = pr + 5 * NR + 1 + NB;
+                A.bfx[l] = q[l]; A.bfy[l] = q[NB + l]; A.pfx[l] = q[2 * NB + l]; A.pfy[l] = q[3 * NB + l];
+                A.bmass[l] = pi[20 + l];
+            }
+        }
     }
+    mid.phase = pi[10]; mid.count = pi[11]; mid.bots_moved = (uint32_t)pi[12]; mid.balls_moved = (uint32_t)pi[13];
+    mid.n_sub = (uint32_t)pi[14]; mid.st_sub = pi[15]; mid.work = pi[16]; mid.hit.r = (uint32_t)pi[17]; mid.hit.b = (uint32_t)pi[18];
     dist_sum0 = pr[5 * NR];
     f_next = pi[0]; prev_moved = (uint32_t)pi[1]; naughty = (uint32_t)pi[2]; st = pi[3]; fz.r = (uint32_t)pi[4]; fz.b = (uint32_t)pi[5];
     fz_bits = (uint32_t)pi[6]; snap_at = pi[7] ? f_next - 1 : -2; snap_moved = (uint32_t)pi[8];
@@ -2334,13 +2354,14 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     Hit fz = { 0, 0 }; // the frozen island (see substep)
     uint32_t fz_bits = 0; // NaughtyBots members + status bits of one computed sub-step of the frozen island (fz_pack_bits)
     int f0 = 0; // first sub-step to run: 0, or where a parked step goes on
+    MidState mid; // (budgeted step: a sub-step parked between two passes of its resolve loop re-enters there)
     constexpr bool FZP = C::NR <= 4 && C::NB <= 8; // what the packed word holds
     bool resumed = false;
     RR_T0();
     if constexpr (BUDGET) {
         resumed = A.i.fzp < 0; // uniform per arena (read after load_record's sync)
         if (RR_UNLIKELY(resumed)) {
-            park_load(A, pk.buf, f0, prev_moved, naughty, st, fz, fz_bits, snap_at, snap_moved, dist_sum0);
+            park_load(A, pk.buf, f0, prev_moved, naughty, st, fz, fz_bits, snap_at, snap_moved, dist_sum0, mid);
             RR_TRACE("E resumed at sub-step %d\n", f0);
         }
     }
@@ -2441,7 +2462,21 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
         Hit hit = { 0, 0 };
         uint32_t n_sub = 0; // what THIS sub-step adds: a freeze keeps it for the frozen sub-steps of later steps
         int st_sub = 0;
-        substep(A, sp, n_sub, st_sub, prev_moved, work, fz, hit);
+        if constexpr (BUDGET) {
+            const bool parked_mid = substep<C, true>(A, sp, n_sub, st_sub, prev_moved, work, fz, hit, &mid, &pk);
+            if (RR_UNLIKELY(parked_mid)) {
+                RR_TRACE("E parked inside sub-step %d before resolve pass %d\n", f, mid.count + 1);
+                park_save(A, pk.buf, f, prev_moved, naughty, st, fz, fz_bits, snap_at == f - 1, snap_moved, dist_sum0, mid);
+                if (RR_IS_LANE0) {
+                    *o.reward() = (O)0; *o.done() = 0;
+                    if (o.reward_g()) *o.reward_g() = (O)0;
+                    if (o.status()) *o.status() = ST_NOT_READY;
+                }
+                return;
+            }
+        } else {
+            substep(A, sp, n_sub, st_sub, prev_moved, work, fz, hit);
+        }
         naughty |= n_sub; st |= st_sub;
 #if defined(RR_PROFILE_PHASES) // diagnostic builds only: the step's contact work in status bits 20-29, "began frozen" in bit 30
         dbg_work_ += work;
@@ -2485,7 +2520,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
         if constexpr (BUDGET) { // over the budget after an expensive sub-step, and more to come: park at this boundary
             if (f + 1 < RR_NUM_SUBSTEPS && RR_UNLIKELY(pk.over(work))) {
                 RR_TRACE("E parked after sub-step %d\n", f);
-                park_save(A, pk.buf, f + 1, prev_moved, naughty, st, fz, fz_bits, snap_at == f, snap_moved, dist_sum0);
+                park_save(A, pk.buf, f + 1, prev_moved, naughty, st, fz, fz_bits, snap_at == f, snap_moved, dist_sum0, mid);
                 if (RR_IS_LANE0) {
                     *o.reward() = (O)0; *o.done() = 0;
                     if (o.reward_g()) *o.reward_g() = (O)0;

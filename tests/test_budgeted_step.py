@@ -1,7 +1,7 @@
 """The budgeted step (rr_sim.hpp: ParkCtx, park_save / park_load; include/roborugby_amd.h: step_budget_clocks).
 
-An arena whose step is over the budget at the end of a physics sub-step parks there and the next call resumes it, ignoring the
-action it is given.  The promise: every arena's trajectory, as a function of the actions it ACCEPTED, is the synchronous
+An arena whose step is over the budget at the end of a physics sub-step -- or between two passes of a sub-step's resolve loop --
+parks there and the next call resumes it, ignoring the action it is given.  The promise: every arena's trajectory, as a function of the actions it ACCEPTED, is the synchronous
 mode's bit for bit.  Checked here on the kernel's own phase source (host-emulated wave), which parks at pseudo-random
 sub-step boundaries -- quiet ones included, at every boundary with park_mod = 1 -- with everything but the persistent record
 overwritten with garbage before each call (what a GPU launch starts from: load_record + derive into an LDS slice that holds
@@ -43,7 +43,7 @@ def _budgeted(preset, state, acts, park_mod, seed, narrow=False, poses=None, **k
             parked += 1
             r = env.step_budget((np.asarray(a) + 3) % 8, park_mod)  # a parked step ignores the new action
             calls += 1
-            assert calls < 40 * len(acts)
+            assert calls < 200 * len(acts)  # (every sub-step boundary and every resolve pass can park: up to ~130 calls per step)
         out.append(_record(env, r))
     return out, parked
 
@@ -117,7 +117,8 @@ def test_parked_step_is_dropped_by_a_state_rewrite_and_survives_nothing_else():
     while r is None:
         r = env.step_budget(d["actions"][0], 1)
         calls += 1
-    assert calls == 12                                           # a whole step again: eleven parks, then the result
+    assert calls >= 12                                           # a whole step again: it parks at each of the eleven inner boundaries
+                                                                 # (and between the passes of its resolve loops), then the result
     ref = el.EmuEnv("T")
     ref.set_state(*state)
     assert _record(ref, ref.step(d["actions"][0])) == _record(env, r)

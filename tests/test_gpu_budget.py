@@ -79,7 +79,7 @@ def test_budgeted_equals_synchronous_on_stuck_chase_arenas(preset):
     for budget in (0, 1, 50_000, 400_000):
         env = rr.BatchedRoboRugbyEnv(n, preset=preset, seed=3, time_limit=True, auto_reset=True, step_budget_clocks=budget)
         env.set_state(d["robots"], d["robots_i"], d["balls"], d["step"])
-        got, calls, nr = _streams(env, table, steps, budget > 0, 400)
+        got, calls, nr = _streams(env, table, steps, budget > 0, 2000)  # (a 1-clock budget parks after every sub-step and resolve pass)
         env.close()
         if ref is None:
             ref = got

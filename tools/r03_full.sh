@@ -21,8 +21,8 @@ run bench_G_f64_from_reset --steps 200 --warmup 20 --no-stagger --no-cpu-baselin
 run bench_T_f64 --preset T --steps 200 --warmup 20 --no-cpu-baseline || exit 1
 run bench_T_f64_from_reset --preset T --steps 200 --warmup 20 --no-stagger --no-cpu-baseline || exit 1
 run bench_G_f64_chase --policy chase --steps 200 --warmup 150 --no-stagger --no-cpu-baseline || exit 1
-run bench_G_f64_chase_budget --policy chase --steps 200 --warmup 150 --no-stagger --no-cpu-baseline --budget 200000 || exit 1
-run bench_G_f64_chase_budget_pipeline2 --policy chase --steps 200 --warmup 150 --no-stagger --no-cpu-baseline --budget 200000 --pipeline 2 || exit 1
+run bench_G_f64_chase_budget --policy chase --steps 200 --warmup 150 --no-stagger --no-cpu-baseline --budget 150000 || exit 1
+run bench_G_f64_chase_budget_pipeline2 --policy chase --steps 200 --warmup 150 --no-stagger --no-cpu-baseline --budget 150000 --pipeline 2 || exit 1
 run bench_T_f64_chase --preset T --policy chase --steps 200 --warmup 150 --no-stagger --no-cpu-baseline || exit 1
 run bench_T_f64_chase_budget --preset T --policy chase --steps 200 --warmup 150 --no-stagger --no-cpu-baseline --budget 100000 || exit 1
 run bench_T_f64_chase_budget_pipeline2 --preset T --policy chase --steps 200 --warmup 150 --no-stagger --no-cpu-baseline --budget 100000 --pipeline 2 || exit 1
