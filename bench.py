@@ -95,22 +95,36 @@ def cpu_baseline(preset, seconds):
 def hbm_copy_probe(dev, mib=1024, iters=20):
     """what a plain device-to-device copy reaches on THIS chip (read + write bytes / HIP-event time),
     quoted next to the 8 TB/s spec as roofline.peak_measured.  One GiB source, one GiB destination, far beyond the 256 MB of
-    Infinity Cache; a few milliseconds in total, outside the timed region."""
+    Infinity Cache; a few milliseconds in total, outside the timed region.  Two probes: the library's 16-B-per-lane grid-stride
+    copy kernel (rr_probe_hbm_copy: the pattern MI355X_MICROARCH.md quotes ~6.3 TB/s for) and torch's copy_ (the runtime's D2D
+    copy).  Returns (GB/s own kernel, GB/s torch copy_)."""
+    import ctypes as C
     import torch
+    from roborugby_amd import _lib
+    lib = _lib.load()
     n = mib * 1024 * 1024 // 4
     src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
     dst = torch.empty_like(src)
-    for _ in range(3):
-        dst.copy_(src)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        dst.copy_(src)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    rates = []
+    for mode in ("kernel", "torch"):
+        def one():
+            if mode == "kernel":
+                _lib.check(lib.rr_probe_hbm_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), C.c_size_t(n * 4), st), "rr_probe_hbm_copy")
+            else:
+                dst.copy_(src)
+        for _ in range(3):
+            one()
+        e0.record()
+        for _ in range(iters):
+            one()
+        e1.record()
+        torch.cuda.synchronize()
+        rates.append(2.0 * n * 4 / (e0.elapsed_time(e1) / iters * 1e-3) / 1e9)
+    assert torch.equal(dst, src)
     del src, dst
-    return 2.0 * n * 4 / (ms * 1e-3) / 1e9
+    return rates[0], rates[1]
 
 
 def pipelined(args):
@@ -333,7 +347,7 @@ def main():
                 traffic = None
         if traffic_source:
             traffic_source += "; a constant from that profiling run, not measured by this bench run"
-        peak_measured = hbm_copy_probe(dev)
+        peak_measured, peak_torch = hbm_copy_probe(dev)
         line = {
             "metric": "env_steps_per_sec", "value": total_steps / dt, "unit": "env-steps/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -359,7 +373,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "peak_measured": peak_measured,
-                         "peak_measured_how": "device-to-device copy of 1 GiB (torch copy_, read + write bytes / HIP-event time), this run",
+                         "peak_measured_how": "device-to-device copy of 1 GiB with a 16-B-per-lane grid-stride kernel (rr_probe_hbm_copy), "
+                                              "read + write bytes / HIP-event time, this run",
+                         "peak_measured_torch_copy": peak_torch,
                          "kernel": "k_step", "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": bytes_per_step,
                          "record_bytes_per_env": env.state_bytes_per_env(),
                          "note": "latency/VALU-bound by construction: 12 dependent sub-steps of fp64 geometry per "

@@ -255,6 +255,10 @@ int rr_dqn_adam_state(rr_dqn *dqn, float *exp_avg, float *exp_avg_sq, int64_t *s
 /* Introspection used by bench.py for the roofline line: bytes of the per-arena HBM record, and how many lanes of
  * a wavefront work on one arena (64 = one wavefront per arena; smaller = several arenas packed per wavefront). */
 int rr_state_bytes_per_env(const rr_env *env, int64_t *bytes);
+/* HBM copy probe for the roofline line: copies `bytes` (a multiple of 16, 16-byte aligned device buffers) from
+ * src to dst with a 16-B-per-lane grid-stride kernel on the current device; the caller times it (HIP events) and quotes
+ * 2 * bytes / time next to the 8 TB/s spec. */
+int rr_probe_hbm_copy(void *dst, const void *src, size_t bytes, void *stream);
 int rr_lanes_per_env(const rr_env *env, int32_t *lanes);
 
 #ifdef __cplusplus

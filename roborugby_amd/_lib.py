@@ -77,6 +77,7 @@ SYMBOLS = {
     "rr_dqn_store": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rr_dqn_act": (C.c_int, [_vp, C.POINTER(_vp * 6), _vp, C.c_int32, C.c_float, C.c_uint64, C.c_uint32, _vp, _vp, _vp]),
     "rr_dqn_adam_state": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_int64), C.c_int32, _vp]),
+    "rr_probe_hbm_copy": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "rr_state_bytes_per_env": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "rr_lanes_per_env": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
 }

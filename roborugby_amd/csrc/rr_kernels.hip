@@ -305,6 +305,14 @@ __global__ void k_policy_chase(const float *obs, int n, int na, uint32_t noise_u
     for (int k = 1; k < na; k++) actions[(size_t)a * na + k] = (int)((c[2 + (k & 1)] >> (4 * (k >> 1))) & 7u);
 }
 
+// HBM copy probe ("confirm on the box with a hipMemcpyDtoD / stream-triad probe"): a plain 16-B-per-lane
+// grid-stride copy, the access pattern MI355X_MICROARCH.md quotes its ~6.3 TB/s for.  bench.py times it with HIP events and
+// reports read + write bytes per second next to the 8 TB/s spec (roofline.peak_measured).
+__global__ __launch_bounds__(256) void k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 struct rr_env {
     rr_config cfg;
@@ -889,6 +897,17 @@ int rr_policy_chase(rr_env *e, const float *obs, const int32_t *step_of, uint32_
     const uint32_t nz = noise >= 1.0f ? 0xFFFFFFFFu : (uint32_t)((double)noise * 4294967296.0);
     hipLaunchKernelGGL(k_policy_chase, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, obs, n, (int)na, nz, seed,
                        e->cfg.arena_offset, step_of, step, actions);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int rr_probe_hbm_copy(void *dst, const void *src, size_t bytes, void *stream) {
+    if (!dst || !src || bytes < 16 || (bytes & 15) || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15))
+        return fail(-1, "rr_probe_hbm_copy: 16-byte aligned buffers and a multiple of 16 bytes, please");
+    const size_t n16 = bytes / 16;
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32; // 32 workgroups per CU, grid-stride over the rest
+    hipLaunchKernelGGL(k_copy16, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4 *)src, (uint4 *)dst, n16);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -155,6 +155,20 @@ def test_config5_learns_to_beat_the_random_policy():
     assert res["epsilon"] == 0.2 and res["learn_calls"] == 599 * 4
 
 
+@pytest.mark.gpu
+def test_config5_learns_under_the_budgeted_step_and_the_pytorch_path_still_trains():
+    """the same loop with the env's budgeted step on: arenas whose step is still in progress report NOT_READY, their rows are no
+    transitions, and the transition they complete later carries the action they accepted -- the agent still learns; and the PyTorch
+    learn path (fused=False: autograd + torch.optim.Adam, what the fused kernels are tested against) still runs the loop."""
+    from roborugby_amd.dqn import train
+    res = train(num_envs=65536, steps=600, device="cuda:0", log_every=0, eval_every=600, eval_envs=8192, step_budget_clocks=100_000)
+    rand, best = res["curve"][0]["random_return"], res["curve"][-1]["greedy_return"]
+    print(f"budgeted step: random {rand:.0f}, greedy after 600 vector steps {best:.0f}; training {res['env_steps_per_sec'] / 1e6:.1f} M env-steps/s")
+    assert res["fused_learn_step"] and best > rand + 1500
+    res2 = train(num_envs=16384, steps=30, device="cuda:0", log_every=0, fused=False)
+    assert not res2["fused_learn_step"] and res2["learn_calls"] == 29 * 4
+
+
 def test_wide_batch_linear_has_the_gradients_of_a_plain_linear():
     """the learn step's split weight-gradient GEMM (dqn._WideBatchLinear): same forward, same gradients up to summation order"""
     import torch
