@@ -308,9 +308,18 @@ __global__ void k_policy_chase(const float *obs, int n, int na, uint32_t noise_u
 // HBM copy probe ("confirm on the box with a hipMemcpyDtoD / stream-triad probe"): a plain 16-B-per-lane
 // grid-stride copy, the access pattern MI355X_MICROARCH.md quotes its ~6.3 TB/s for.  bench.py times it with HIP events and
 // reports read + write bytes per second next to the 8 TB/s spec (roofline.peak_measured).
-__global__ __launch_bounds__(256) void k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy16(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, size_t n16) {
+    // four independent 16-B loads in flight per lane, then the four stores (a wavefront moves 4 KB per round)
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const u32x4 a = __builtin_nontemporal_load(&src[i]), b = __builtin_nontemporal_load(&src[i + stride]);
+        const u32x4 c = __builtin_nontemporal_load(&src[i + 2 * stride]), d = __builtin_nontemporal_load(&src[i + 3 * stride]);
+        __builtin_nontemporal_store(a, &dst[i]); __builtin_nontemporal_store(b, &dst[i + stride]);
+        __builtin_nontemporal_store(c, &dst[i + 2 * stride]); __builtin_nontemporal_store(d, &dst[i + 3 * stride]);
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -906,8 +915,8 @@ int rr_probe_hbm_copy(void *dst, const void *src, size_t bytes, void *stream) {
         return fail(-1, "rr_probe_hbm_copy: 16-byte aligned buffers and a multiple of 16 bytes, please");
     const size_t n16 = bytes / 16;
     size_t blocks = (n16 + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32; // 32 workgroups per CU, grid-stride over the rest
-    hipLaunchKernelGGL(k_copy16, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4 *)src, (uint4 *)dst, n16);
+    if (blocks > 256 * 16) blocks = 256 * 16; // 16 workgroups per CU, grid-stride over the rest
+    hipLaunchKernelGGL(k_copy16, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4 *)src, (u32x4 *)dst, n16);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -447,6 +447,7 @@ def train(num_envs=65536, steps=300, preset="T", device="cuda:0", seed=0, checkp
     t0 = time.perf_counter()
     t_eval = 0.0
     score_sum = torch.zeros(num_envs, device=device)
+    real_rows = torch.zeros((), dtype=torch.int64, device=device)  # rows that were transitions (not re-placements, not NOT_READY)
     overlap = bool(overlap_learn and learn and torch.device(device).type == "cuda")
     main_stream = torch.cuda.current_stream(torch.device(device))
     side = torch.cuda.Stream(device=torch.device(device)) if overlap else None
@@ -477,6 +478,7 @@ def train(num_envs=65536, steps=300, preset="T", device="cuda:0", seed=0, checkp
             if grumpy:
                 accepted_g = action_grumpy
         score_sum += reward
+        real_rows += real.sum()
         if learn:
             if learned is not None:
                 main_stream.wait_event(learned)  # the sampled rows are read, Q_eval is written: the ring and the net are ours again
@@ -511,7 +513,12 @@ def train(num_envs=65536, steps=300, preset="T", device="cuda:0", seed=0, checkp
         os.makedirs(os.path.dirname(os.path.abspath(checkpoint)), exist_ok=True)
         torch.save(dict(agent=agent.state_dict(), env_state=env.get_state(), episode=env.get_episode_state()), checkpoint)
     lr_, _, ll, cnt = env.episode_stats()
-    res = dict(env_steps_per_sec=num_envs * steps / dt, seconds=dt, num_envs=num_envs, steps=steps,
+    n_real = int(real_rows.item())
+    # env steps = the rows that stepped an arena (auto-reset calls count, as in bench.py's random line they are subtracted only there;
+    # NOT_READY rows of the budgeted step never count)
+    env_steps = num_envs * steps if not step_budget_clocks else n_real
+    res = dict(env_steps_per_sec=env_steps / dt, seconds=dt, num_envs=num_envs, steps=steps, transitions=n_real,
+               step_budget_clocks=step_budget_clocks,
                learn_calls=agent.updates, updates_per_step=updates_per_step if learn else 0, batch_size=B,
                samples_per_transition=(updates_per_step * B / (num_envs * n_teams)) if learn else 0.0, overlap_learn=overlap,
                replay_transitions=agent.mem_size, target_update_freq=agent.target_update_freq, target_syncs=agent.target_syncs,
