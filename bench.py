@@ -29,7 +29,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--arenas", type=int, default=65536, help="arenas per GPU (weak scaling)")
-    ap.add_argument("--preset", default="G", choices=["G", "T"],
+    ap.add_argument("--preset", default="G", choices=["G", "T", "D"],
                     help="G = constants as checked in (2+2 robots, 4+4 balls, 800x800); T = DQN training preset")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--policy", default="random", choices=["random", "chase"])

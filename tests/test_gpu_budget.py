@@ -141,3 +141,78 @@ def test_budget_rejects_what_it_cannot_bracket():
     with pytest.raises(_lib.RRError, match="reward stack"):
         env.set_step_budget(1000)
     env.close()
+
+
+def test_budgeted_step_with_its_policy_can_be_captured_into_a_hip_graph():
+    """the budgeted rr_step and the chase policy only enqueue kernels on the caller's stream: captured once, replayed, same streams
+    of outputs as eager calls (the clock decides who parks, so the two envs are compared through their action-aligned streams)"""
+    import roborugby_amd as rr
+    from roborugby_amd import players
+    n, steps = 8192, 12
+    env = rr.BatchedRoboRugbyEnv(n, preset="T", seed=5, step_budget_clocks=60_000)
+    obs = env.reset()
+    out = (obs.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, dtype=torch.uint8, device="cuda"), None,
+           torch.zeros(n, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda"))
+    acts = torch.zeros(n, 1, dtype=torch.int32, device="cuda")
+    accepted = torch.zeros(n, dtype=torch.int32, device="cuda")   # per-arena count of accepted steps: the policy's step index
+
+    def body():
+        players.chase(env, out[0], step_of=accepted, noise=0.1, seed=3, out=acts)
+        env.step(acts, out=out)
+        accepted.add_(((out[5] & NOT_READY) == 0).to(torch.int32))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        body()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        body()
+    for _ in range(200):
+        g.replay()
+    torch.cuda.synchronize()
+    assert int(accepted.min()) > 20 and int(accepted.max()) <= 201  # (stuck arenas park dozens of times per step at this budget)
+    # the same arenas stepped synchronously with the same policy reach the same observation after the same number of accepted steps
+    ref = rr.BatchedRoboRugbyEnv(n, preset="T", seed=5)
+    o = ref.reset()
+    k = int(accepted.min())
+    cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+    for s in range(k):
+        a = players.chase(ref, o, step_of=cnt, noise=0.1, seed=3)
+        o, r, d, info = ref.step(a)
+        cnt += 1
+    sel = accepted == k
+    assert int(sel.sum()) > 0 and torch.equal(out[0][sel], o[sel])
+    env.close(); ref.close()
+
+
+def test_chase_policy_kernel_is_the_documented_rule():
+    import roborugby_amd as rr
+    from roborugby_amd import players
+    n = 65536
+    env = rr.BatchedRoboRugbyEnv(n, preset="G", seed=1)
+    obs = env.reset()
+    a = players.chase(env, obs, step=1, noise=0.0)
+    d = (obs[:, 1] - obs[:, 0] + 540.0) % 360.0 - 180.0
+    want = torch.where(d.abs() < 8, 0, torch.where(d > 0, 2, 3)).to(torch.int32)
+    assert a.shape == (n, 4) and torch.equal(a[:, 0], want)
+    hist = torch.bincount(a[:, 1:].reshape(-1).long(), minlength=8).float() / (3 * n)
+    assert float((hist - 0.125).abs().max()) < 0.01                      # the other robots act uniformly at random
+    b = players.chase(env, obs, step=1, noise=0.25)
+    assert abs(float((b[:, 0] != want).float().mean()) - 0.25 * 7 / 8) < 0.01
+    assert torch.equal(players.chase(env, obs, step=1, noise=0.25), b)   # a function of (seed, arena, step) ...
+    assert not torch.equal(players.chase(env, obs, step=2, noise=0.25), b)  # ... and nothing else
+    env.close()
+
+
+def test_hbm_copy_probe_copies():
+    import ctypes as C
+    from roborugby_amd import _lib
+    lib = _lib.load()
+    src = torch.randn(1 << 22, device="cuda")
+    dst = torch.zeros_like(src)
+    _lib.check(lib.rr_probe_hbm_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), C.c_size_t(src.numel() * 4),
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rr_probe_hbm_copy")
+    torch.cuda.synchronize()
+    assert torch.equal(dst, src)
+    assert lib.rr_probe_hbm_copy(C.c_void_p(dst.data_ptr() + 4), C.c_void_p(src.data_ptr()), C.c_size_t(64), None) == -1

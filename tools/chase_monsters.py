@@ -15,6 +15,13 @@ budget = int(sys.argv[5]) if len(sys.argv) > 5 else 0  # the budgeted step (shad
 n = 65536
 env = rr.BatchedRoboRugbyEnv(n, preset=preset, seed=0, step_budget_clocks=budget)
 obs = env.reset()
+if os.environ.get("RR_STAGGER"):  # steady state of a long rollout: random episode phases + one whole episode of pre-roll (like bench.py)
+    st = env.get_state()
+    T = env.preset.game_len_steps
+    gg = torch.Generator(device='cuda'); gg.manual_seed(7)
+    env.set_state(st["robots"], st["robots_i"], st["balls"], torch.randint(0, T, (n,), generator=gg, device='cuda', dtype=torch.int32))
+    for i in range(T + 1):
+        obs = env.step(torch.randint(0, 8, (n, env.preset.nr), generator=gg, device='cuda', dtype=torch.int32))[0]
 lib = _lib.load()
 na = env.preset.nr
 apw = 64 // env.lanes_per_env()
@@ -63,6 +70,14 @@ print(f"{preset} {policy}: wavefront run time us  p50 {pct[:,0].mean():.0f}  p90
 print("slowest wave per step (step, wave, us):", [(f['step'], f['wave'], int(f['us'])) for f in found])
 for f in found[::4]:
     print("  step", f['step'], "wave", f['wave'], int(f['us']), "us: work", f['work'].tolist(), "began frozen", f['frozen'].tolist())
+# how the wavefront time relates to the contact work of its arenas (last step): mean duration by the wavefront's total / max work
+w_all = ((stw >> 20) & 1023).cpu().numpy().reshape(waves, apw)
+tot, mx = w_all.sum(1), w_all.max(1)
+for lo, hi in ((0, 0), (1, 3), (4, 11), (12, 47), (48, 10 ** 6)):
+    m = (mx >= lo) & (mx <= hi)
+    if m.any():
+        print(f"  wavefronts whose busiest arena did {lo}..{hi} work units: {int(m.sum())} ({100.0 * m.mean():.1f} %), mean {d[m].mean():.1f} us, p90 {np.percentile(d[m], 90):.1f} us")
+print("  arenas with work > 0: %.2f %%; wavefronts with any: %.1f %%" % (100.0 * (w_all > 0).mean(), 100.0 * (mx > 0).mean()))
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 np.savez(os.path.join(ROOT, 'gpurun_out', f'chase_monsters_{preset}.npz' if policy == 'chase' else f'{policy}_monsters_{preset}.npz'), pct=pct, **slow_rec,
          **{f"{k}_{i}": v for i, f in enumerate(found) for k, v in f.items()})
