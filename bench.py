@@ -250,16 +250,23 @@ def main():
         # arena at the same, contact-poor start of its episode) -- kept so that the lines stay comparable across rounds
         for i in range(W):
             env.step(acts[i], out=out)
+        ev0 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
         rrd.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(K):
+            ev0[i][0].record()
             env.step(acts[W + i], out=out)
+            ev0[i][1].record()
         torch.cuda.synchronize()
         rrd.barrier()
         dt0 = rrd.reduce_max(time.perf_counter() - t0, dev)
-        from_reset = {"value": rrd.reduce_sum(float(n * K), dev) / dt0, "ms_per_step": dt0 / K * 1e3,
-                      "note": f"{K} steps right after a fresh reset (steps {W + 1}..{W + K} of the episode), same process, before the pre-roll"}
+        k0 = rrd.reduce_max(sum(a.elapsed_time(b) for a, b in ev0) / K, dev)
+        ach0 = p.algorithmic_bytes_per_step(na) * n / (k0 * 1e-3) / 1e9
+        from_reset = {"value": rrd.reduce_sum(float(n * K), dev) / dt0, "ms_per_step": dt0 / K * 1e3, "kernel_ms": k0,
+                      "roofline_achieved": ach0, "roofline_frac": ach0 / HBM_PEAK_GBS,
+                      "note": f"{K} steps right after a fresh reset (steps {W + 1}..{W + K} of the episode), same process, before the "
+                              "pre-roll: the definition of rounds 1-2 (r02: 184.2 M, frac 0.01415)"}
     if stagger:
         # Steady state: every arena at a uniformly random phase of its episode, with the state a rollout of that length leaves
         # (contacts accumulate late in an episode: robots park balls against walls).  The step counters are spread over
