@@ -1913,8 +1913,11 @@ RR_HDN void observe_both(Arena<C> &A, const SimParams<typename C::Real> &sp, O *
     static_assert(6 * C::NR <= 4 * C::NB && 6 <= C::NB, "the second team's lidar scratch aliases bfx..pfy / exc");
     static_assert(offsetof(ArenaBody<C>, pfy) == offsetof(ArenaBody<C>, bfx) + 3 * C::NB * sizeof(R), "bfx, bfy, pfx, pfy are contiguous");
     constexpr int NT1 = 3 * C::NR;
-    R *cand[2][2] = { { A.u.lidar[0], A.u.lidar[1] }, { &A.bfx[0], &A.bfx[0] + NT1 } }; // [team][front|back][ray, rect]
-    R *lids[2] = { A.lid, A.exc };
+    // [team][front|back][ray, rect] candidates and the two teams' capped minima, as SELECTED addresses: a runtime-indexed array of
+    // pointers lands in scratch memory -- 48 B per lane written by every wavefront (that was the kernel's whole "scratch" and
+    // 256 B of HBM write traffic per arena) and turns the accesses into flat loads / stores
+    auto cand = [&](int tm, int fb) -> R * { return tm == 0 ? (fb == 0 ? &A.u.lidar[0][0] : &A.u.lidar[1][0]) : (fb == 0 ? &A.bfx[0] : &A.bfx[0] + NT1); };
+    auto lids = [&](int tm) -> R * { return tm == 0 ? &A.lid[0] : &A.exc[0]; };
     RR_FOR_LANES(l) { if (l < C::NR) A.irot[l] = (R)NAN; } // the candidates below overwrite the aliased inner-square offsets
     RR_SYNC();
     ensure_sides(A);
@@ -1956,8 +1959,8 @@ RR_HDN void observe_both(Arena<C> &A, const SimParams<typename C::Real> &sp, O *
                     if (de <= ds && de < bf) bf = de;
                     if (ds <= de && ds < bb) bb = ds;
                 }
-                cand[tm][0][t] = bf;
-                cand[tm][1][t] = bb;
+                cand(tm, 0)[t] = bf;
+                cand(tm, 1)[t] = bb;
             }
         }
     }
@@ -1967,14 +1970,14 @@ RR_HDN void observe_both(Arena<C> &A, const SimParams<typename C::Real> &sp, O *
             const int t2 = base + l;
             if (t2 < 12) {
                 const int tm = t2 / 6, t = t2 % 6;
-                const R *src = cand[tm][t & 1];
+                const R *src = cand(tm, t & 1);
                 const int k = t >> 1;
                 R best = inf_<R>();
                 for (int q = 0; q < C::NR; q++) {
                     R v = src[k * C::NR + q];
                     if (v < best) best = v;
                 }
-                lids[tm][t] = py_min<R>(best, (R)150);
+                lids(tm)[t] = py_min<R>(best, (R)150);
             }
         }
     }
@@ -1987,7 +1990,7 @@ RR_HDN void observe_both(Arena<C> &A, const SimParams<typename C::Real> &sp, O *
             const int ridx = l == 0 ? 0 : C::NRH;
             O *out = l == 0 ? out_h : out_g;
             R lid[6]; // (by value: the team's staged output row reuses this very array below)
-            for (int k = 0; k < 6; k++) lid[k] = lids[l][k];
+            for (int k = 0; k < 6; k++) lid[k] = lids(l)[k];
             V2<R> rc = { A.p.rcx[ridx], A.p.rcy[ridx] }, bc = { A.p.bcx[0], A.p.bcy[0] };
             V2<R> good = { sp.W, sp.H }, bad = { (R)0, (R)0 };
             R ball_angle = angle_degrees<R>(rc, bc, lst);
@@ -2004,7 +2007,7 @@ RR_HDN void observe_both(Arena<C> &A, const SimParams<typename C::Real> &sp, O *
             }
             // staged (see observe()): each team's row is parked in the array its minima came from -- A.lid / A.exc, read into
             // registers above by this very lane -- and leaves as lane-strided runs below
-            O *row = STAGED ? reinterpret_cast<O *>(lids[l]) : out;
+            O *row = STAGED ? reinterpret_cast<O *>(lids(l)) : out;
             row[0] = (O)bot_angle; row[1] = (O)ball_angle; row[2] = (O)ball_dist; row[3] = (O)goal_angle; row[4] = (O)goal_dist;
             row[5] = (O)lid[0]; row[6] = (O)lid[2]; row[7] = (O)lid[4]; row[8] = (O)lid[1]; row[9] = (O)lid[5]; row[10] = (O)lid[3];
         }
@@ -2016,8 +2019,8 @@ RR_HDN void observe_both(Arena<C> &A, const SimParams<typename C::Real> &sp, O *
         for (int base = 0; base < 22; base += C::VW) {
             RR_FOR_LANES(l) {
                 const int k = base + l;
-                if (k < 11) out_h[k] = reinterpret_cast<const O *>(lids[0])[k];
-                else if (k < 22) out_g[k - 11] = reinterpret_cast<const O *>(lids[1])[k - 11];
+                if (k < 11) out_h[k] = reinterpret_cast<const O *>(lids(0))[k];
+                else if (k < 22) out_g[k - 11] = reinterpret_cast<const O *>(lids(1))[k - 11];
             }
         }
         RR_SYNC();
