@@ -66,6 +66,6 @@ json.dump(out, open(f"{out_dir}/{key}_summary.json", "w"), indent=1)
 tf = "profiles/traffic.json"
 t = json.load(open(tf)) if os.path.exists(tf) else {}
 t[key] = {"bytes": 2 * f_ + w_, "source": f"{out_dir}/{key}_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, "
-                                            f"tools/profile_r01.sh {tag})"}
+                                            f"tools/r03_profile.sh {tag})"}
 json.dump(t, open(tf, "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("avg_ns", "hbm_bytes_per_env_step")}))
