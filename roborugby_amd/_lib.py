@@ -12,6 +12,7 @@ import torch  # noqa: F401  (import order matters)
 HERE = os.path.dirname(os.path.abspath(__file__))
 # RR_LIB_PATH lets tools/ A/B-test alternative builds of the same ABI (kernel tuning); default = the in-tree build
 LIB_PATH = os.environ.get("RR_LIB_PATH", os.path.join(HERE, "libroborugby_amd.so"))
+LIB_PATH_EXACT = os.path.join(HERE, "libroborugby_amd_exact.so")  # the exact-trig parity build (build.py: -DRR_EXACT_TRIG=1)
 
 
 class RRConfig(C.Structure):
@@ -43,6 +44,7 @@ _vp = C.c_void_p
 SYMBOLS = {
     "rr_abi_version": (C.c_int, []),
     "rr_last_error": (C.c_char_p, []),
+    "rr_exact_trig": (C.c_int, []),
     "rr_create": (C.c_int, [C.POINTER(RRConfig), C.POINTER(_vp)]),
     "rr_destroy": (C.c_int, [_vp]),
     "rr_reset": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
@@ -83,34 +85,45 @@ SYMBOLS = {
 }
 
 _lib = None
+_lib_exact = None
 
 
-def load():
-    """Loads libroborugby_amd.so (built by roborugby_amd.build / __graft_entry__.build)."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load(exact=False):
+    """Loads libroborugby_amd.so (built by roborugby_amd.build / __graft_entry__.build); exact=True: the exact-trig parity build
+    libroborugby_amd_exact.so (same ABI, same sources, -DRR_EXACT_TRIG=1)."""
+    global _lib, _lib_exact
+    if exact:
+        if _lib_exact is None:
+            _lib_exact = _load_path(LIB_PATH_EXACT, True)
+        return _lib_exact
+    if _lib is None:
+        _lib = _load_path(LIB_PATH, False)
+    return _lib
+
+
+def _load_path(path, exact):
     from . import build as _build
-    stale = "RR_LIB_PATH" not in os.environ and os.path.exists(LIB_PATH) and _build.sources_present() and _build.is_stale()
-    if not os.path.exists(LIB_PATH) or stale:
+    overridden = not exact and "RR_LIB_PATH" in os.environ
+    stale = not overridden and os.path.exists(path) and _build.sources_present() and _build.is_stale(exact)
+    if not os.path.exists(path) or stale:
         # not a fallback: the only thing ever loaded is the HIP library, (re)built here if the in-tree .so is absent or
         # older than its sources (an edited rr_sim.hpp must never be tested against yesterday's kernels)
         try:
-            if "RR_LIB_PATH" in os.environ:
+            if overridden:
                 raise RuntimeError("RR_LIB_PATH points to a missing file")
-            _build.build_hip_library(verbose=True)
+            _build.build_hip_library(verbose=True, exact=exact)
         except Exception as exc:
             if stale:
-                raise ImportError(f"{LIB_PATH} is older than its sources and could not be rebuilt ({exc})") from exc
+                raise ImportError(f"{path} is older than its sources and could not be rebuilt ({exc})") from exc
             raise ImportError(
-                f"{LIB_PATH} is missing and could not be built ({exc}): run `python -m roborugby_amd.build`. "
+                f"{path} is missing and could not be built ({exc}): run `python -m roborugby_amd.build`. "
                 "roborugby_amd has no CPU fallback.") from exc
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    assert lib.rr_exact_trig() == (1 if exact else 0) or overridden, path
     return lib
 
 
@@ -118,7 +131,8 @@ class RRError(RuntimeError):
     pass
 
 
-def check(rc, what):
+def check(rc, what, lib=None):
     if rc != 0:
-        msg = load().rr_last_error()
+        libs = [lib] if lib is not None else [x for x in (_lib, _lib_exact) if x is not None] or [load()]
+        msg = b"; ".join(m for m in (x.rr_last_error() for x in libs) if m)
         raise RRError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")

@@ -398,6 +398,7 @@ static inline dim3 wave_block() { return dim3(64 * WAVES_PER_BLOCK); }
 extern "C" {
 
 int rr_abi_version(void) { return RR_ABI_VERSION; }
+int rr_exact_trig(void) { return RR_EXACT_TRIG; }
 const char *rr_last_error(void) { return g_err.c_str(); }
 
 int rr_create(const rr_config *cfg, rr_env **out) {

@@ -162,6 +162,52 @@ RR_HD float m_rint(float x) { return ::rintf(x); }
 // a few pi here: angles are degrees in [-90, 810) converted to radians).  Absolute error < 1e-16, which is what
 // matters for corner offsets of length ~22; much cheaper in registers and instructions than the generic ocml
 // path with its Payne-Hanek fallback, and identical on the host emulation and on the GPU.
+#ifndef RR_EXACT_TRIG
+#define RR_EXACT_TRIG 0
+#endif
+#if RR_EXACT_TRIG
+// The "exact trig" build (libroborugby_amd_exact.so, BatchedRoboRugbyEnv(exact_trig=True)): sin & cos to ~2^-63 of their true values
+// before the one final rounding, i.e. correctly rounded except on ~1 argument in 10^4.  Why: the reference's math.sin / math.cos
+// (glibc) are within 0.55 ulp and return the correctly rounded value for 99.86 % of this path's arguments; the fast routine below
+// (Cody-Waite + fdlibm kernels, < 1 ulp) agrees with glibc on 97.0 % of them, this one on 99.81 % -- and a 1-ulp difference in
+// a robot's move is what eventually makes a free-running episode leave the reference's trajectory (DESIGN.md section 2,
+// profiles/r03/divergence_attribution.txt: the first cause in 21 of 25 departures).  Double-double arithmetic from exactly specified
+// operations only (+, *, fma), so GPU and host emulation still agree bit for bit.  ~4x the instructions of the fast routine:
+// an opt-in parity build, not the default.
+struct DD { double h, l; };
+RR_HD DD dd_two_sum(double a, double b) { const double s = a + b, bb = s - a; DD r = { s, (a - (s - bb)) + (b - bb) }; return r; }
+RR_HD DD dd_fast_two_sum(double a, double b) { const double s = a + b; DD r = { s, b - (s - a) }; return r; }
+RR_HD DD dd_two_prod(double a, double b) { const double p = a * b; DD r = { p, ::fma(a, b, -p) }; return r; }
+RR_HD DD dd_add(DD a, DD b) { const DD s = dd_two_sum(a.h, b.h); return dd_fast_two_sum(s.h, a.l + b.l + s.l); }
+RR_HD DD dd_add_d(DD a, double b) { const DD s = dd_two_sum(a.h, b); return dd_fast_two_sum(s.h, s.l + a.l); }
+RR_HD DD dd_mul(DD a, DD b) { const DD p = dd_two_prod(a.h, b.h); return dd_fast_two_sum(p.h, ::fma(a.h, b.l, ::fma(a.l, b.h, p.l))); }
+RR_HD DD dd_mul_d(DD a, double b) { const DD p = dd_two_prod(a.h, b); return dd_fast_two_sum(p.h, ::fma(a.l, b, p.l)); }
+RR_HD void m_sincos(double x, double &s, double &c) {
+    const double fn = ::rint(x * 6.36619772367581382433e-01);
+    const int n = (int)fn;
+    // y = x - fn * pi/2 with pi/2 = P1 + P2 + P3 (33 + 33 + 53 bits; fn * P1 and fn * P2 are exact for the few turns seen here)
+    const double P1 = 1.57079632673412561417e+00, P2 = 6.07710050630396597660e-11, P3 = 2.02226624879595063154e-21;
+    DD y = dd_add(dd_two_sum(::fma(-fn, P1, x), -fn * P2), dd_two_prod(-fn, P3));
+    const DD z = dd_mul(y, y);
+    // sin y = y + y^3 (S1 + z (S2 + z Q(z))), cos y = 1 - z/2 + z^2 (C1 + z (C2 + z R(z))): Taylor coefficients, the two leading ones of
+    // each series in double-double (the tails contribute < 2^-66 of the result each)
+    const DD S1 = { -1.66666666666666657415e-01, -9.25185853854297065662e-18 }, S2 = { 8.33333333333333321769e-03, 1.15648231731787138300e-19 };
+    const double S3 = -1.98412698412698412526e-04, S4 = 2.75573192239858925110e-06, S5 = -2.50521083854417202239e-08,
+                 S6 = 1.60590438368216133188e-10, S7 = -7.64716373181981641101e-13, S8 = 2.81145725434552059500e-15;
+    const DD C1 = { 4.16666666666666643537e-02, 2.31296463463574266163e-18 }, C2 = { -1.38888888888888894189e-03, 5.30054395437357706435e-20 };
+    const double C3 = 2.48015873015873015658e-05, C4 = -2.75573192239858882758e-07, C5 = 2.08767569878680989792e-09,
+                 C6 = -1.14707455977297245138e-11, C7 = 4.77947733238738524956e-14, C8 = -1.56192069685862252710e-16;
+    const double zh = z.h;
+    const double qs = ::fma(zh, ::fma(zh, ::fma(zh, ::fma(zh, ::fma(zh, S8, S7), S6), S5), S4), S3);
+    const double qc = ::fma(zh, ::fma(zh, ::fma(zh, ::fma(zh, ::fma(zh, C8, C7), C6), C5), C4), C3);
+    const DD sn = dd_add(y, dd_mul(dd_mul(y, z), dd_add(S1, dd_mul(z, dd_add_d(S2, zh * qs)))));
+    const DD cs = dd_add(dd_add_d(dd_mul_d(z, -0.5), 1.0), dd_mul(dd_mul(z, z), dd_add(C1, dd_mul(z, dd_add_d(C2, zh * qc)))));
+    const double ks = sn.h + sn.l, kc = cs.h + cs.l;
+    const int q = n & 3;
+    s = (q == 0) ? ks : (q == 1) ? kc : (q == 2) ? -ks : -kc;
+    c = (q == 0) ? kc : (q == 1) ? -ks : (q == 2) ? -kc : ks;
+}
+#else
 RR_HD void m_sincos(double x, double &s, double &c) {
     // explicit fused multiply-adds (the build runs with -ffp-contract=off so that the REFERENCE arithmetic is never
     // contracted; this routine is ours, and fma is exactly specified, so GPU and host emulation still agree bit for bit)
@@ -188,6 +234,7 @@ RR_HD void m_sincos(double x, double &s, double &c) {
     s = (q == 0) ? ks : (q == 1) ? kc : (q == 2) ? -ks : -kc;
     c = (q == 0) ? kc : (q == 1) ? -ks : (q == 2) ? -kc : ks;
 }
+#endif
 RR_HD void m_sincos(float x, float &s, float &c) { s = ::sinf(x); c = ::cosf(x); }
 
 template <typename R> RR_HD R inf_() { return (R)INFINITY; }

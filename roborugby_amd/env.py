@@ -102,7 +102,7 @@ class BatchedRoboRugbyEnv:
     def __init__(self, num_envs, preset="T", device=None, seed=0, time_limit=True, auto_reset=True, dtype="f64",
                  arena_offset=0, env_id="RoboRugbySimpleDuel-v3", reset_on_fault=None, action_mode="discrete",
                  rewards=SIMPLE_DUEL3_REWARDS, observer="SingleBall_6wayLidar_v2", lst_starting_config=None,
-                 goal_scoring=False, step_budget_clocks=0):
+                 goal_scoring=False, step_budget_clocks=0, exact_trig=False):
         self.preset = PRESETS[preset] if isinstance(preset, str) else preset
         assert isinstance(self.preset, Preset)
         if not torch.cuda.is_available():
@@ -118,7 +118,12 @@ class BatchedRoboRugbyEnv:
         # auto-reset re-places the arena; default: on exactly when auto_reset is
         self.reset_on_fault = bool(auto_reset if reset_on_fault is None else reset_on_fault)
         p = self.preset
-        self._lib = _lib.load()
+        # exact_trig=True: the exact-trig parity build (libroborugby_amd_exact.so, same ABI): sin / cos of the robot kinematics ~correctly
+        # rounded, so free-running episodes follow the reference bit for bit far longer; slower, fp64 only
+        self.exact_trig = bool(exact_trig)
+        if self.exact_trig and dtype != "f64":
+            raise ValueError("exact_trig is a property of the fp64 parity mode")
+        self._lib = _lib.load(exact=self.exact_trig)
         cfg = _lib.RRConfig(
             struct_size=C.sizeof(_lib.RRConfig), num_envs=self.num_envs, nr_happy=p.nr_happy, nr_grumpy=p.nr_grumpy,
             nb_pos=p.nb_pos, nb_neg=p.nb_neg, arena_w=p.arena_w, arena_h=p.arena_h, game_len_steps=p.game_len_steps,

@@ -1,0 +1,77 @@
+"""The exact-trig parity build (-DRR_EXACT_TRIG=1: libroborugby_amd_exact.so; here the host-emulated wave compiled the same way).
+
+The kernel's default sin / cos (Cody-Waite + fdlibm kernels, < 1 ulp) agrees with the reference's math.sin / math.cos (glibc) on 97 % of
+this path's arguments, and that 1-ulp difference in a robot's move is the first cause of most departures of free-running episodes
+from the reference (profiles/r03/divergence_attribution.txt).  The exact build evaluates them in double-double (~2^-63 before the one
+final rounding): it must be correctly rounded on practically every argument, agree with glibc on >= 99.7 %, leave every single-step
+parity result where it was, and make whole golden episodes follow the reference BIT FOR BIT where the default build leaves them."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import emu_lib as el
+import oracle_lib as ol
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "tools"))
+import attribute_divergence as ad  # noqa: E402
+
+
+def _sincos(lib, x):
+    import ctypes as C
+    s, c = C.c_double(), C.c_double()
+    lib.emu_sincos(float(x), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def test_exact_sincos_is_correctly_rounded_and_agrees_with_glibc():
+    rng = np.random.RandomState(5)
+    deg = np.concatenate([rng.uniform(-90, 810, 60000), (rng.randint(0, 361, 60000) + 0.6 * rng.randint(-2000, 2000, 60000)) % 360.0 + 90.0 * rng.randint(0, 2, 60000)])
+    x = deg * (np.pi / 180.0)
+    ex, fa = el.lib(exact=True), el.lib()
+    got = np.array([_sincos(ex, v) for v in x])
+    fast = np.array([_sincos(fa, v) for v in x])
+    ld = x.astype(np.longdouble)
+    cr = np.stack([np.sin(ld).astype(np.float64), np.cos(ld).astype(np.float64)], 1)  # 64-bit mantissa, rounded once more: ~CR
+    gl = np.stack([np.sin(x), np.cos(x)], 1)                                            # libm = what the reference calls
+    miss_cr, miss_gl, fast_gl = (got != cr).mean(), (got != gl).mean(), (fast != gl).mean()
+    print(f"exact sin/cos: != correctly rounded {100 * miss_cr:.3f} %, != glibc {100 * miss_gl:.3f} % (default routine != glibc {100 * fast_gl:.2f} %)")
+    assert miss_cr < 1.5e-3 and miss_gl < 3e-3 and fast_gl > 0.02
+    assert np.abs(got - cr).max() < 2.3e-16
+
+
+@pytest.mark.parametrize("preset,want", [("T", 13), ("G", 3), ("D", 4)])
+def test_exact_trig_follows_whole_golden_episodes_bit_for_bit(golden_dir, preset, want):
+    t = dict(np.load(f"{golden_dir}/traj_{preset}.npz"))
+    t["_preset"] = preset
+    na_used = (t["actions"][:, 0, :] >= 0).sum(1)
+    full = np.nonzero(na_used == na_used.max())[0]
+    na = int(na_used.max())
+    fast = [ad.free_run(lambda: el.EmuEnv(preset), t, ep, na) for ep in full]
+    exact = [ad.free_run(lambda: el.EmuEnv(preset, exact=True), t, ep, na) for ep in full]
+    n_fast, n_exact = sum(x is None for x in fast), sum(x is None for x in exact)
+    print(f"[{preset}] free-running golden episodes bit-identical to the reference to their last step: default build {n_fast}, exact-trig build "
+          f"{n_exact} of {len(full)}; first departures (exact): {[x for x in exact if x is not None]}")
+    assert n_exact >= want and n_exact > n_fast
+    later = sum(1 for a, b in zip(fast, exact) if a is not None and (b is None or b >= a))
+    assert later >= sum(a is not None for a in fast) - 1  # (an episode may leave a little earlier by chance; not the rule)
+
+
+@pytest.mark.parametrize("preset", ["T", "G"])
+def test_exact_trig_keeps_single_step_parity(golden_dir, preset):
+    """every 7th golden step from the reference's dumped state: same bar as the default build (tests/test_emulated_wave.py)"""
+    t = np.load(f"{golden_dir}/traj_{preset}.npz")
+    worst = 0.0
+    idx = [(ep, s) for ep in range(t["length"].shape[0]) for s in range(int(t["length"][ep]))][::7]
+    for ep, s in idx:
+        na = int((t["actions"][ep, s] >= 0).sum())
+        e = el.EmuEnv(preset, exact=True)
+        e.set_state(t["state_robots"][ep, s], t["state_robots_i"][ep, s], t["state_balls"][ep, s], int(t["state_step"][ep, s]))
+        r = e.step(t["actions"][ep, s, :na])
+        st = e.get_state()
+        assert np.array_equal(st["robots_i"], t["state_robots_i"][ep, s + 1])
+        worst = max(worst, float(np.nanmax(np.abs(st["robots"] - t["state_robots"][ep, s + 1]))), float(np.abs(st["balls"] - t["state_balls"][ep, s + 1]).max()),
+                    float(np.abs(r["obs"] - t["obs"][ep, s]).max()))
+    assert worst < 1e-9, worst
