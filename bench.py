@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--budget", type=int, default=0, help="extension, not the headline: the budgeted step (rr_config.step_budget_clocks, "
                     "shader clocks): an arena over the budget after an expensive sub-step parks and reports NOT_READY; such rows are "
                     "NOT counted as env steps")
+    ap.add_argument("--exact-trig", action="store_true", help="the exact-trig parity build (libroborugby_amd_exact.so): sin / cos of the "
+                    "kinematics in double-double, ~correctly rounded; not the headline library")
     ap.add_argument("--no-stagger", action="store_true", help="time the steps right after a fresh reset (every arena at the same, "
                     "contact-poor episode phase).  Default: arenas at uniformly random episode phases, reached by a pre-roll of "
                     "one whole episode outside the timed region -- the steady state of a long rollout")
@@ -215,7 +217,8 @@ def main():
     dev = torch.device(f"cuda:{local_dev}")
     n = args.arenas
     env = rr.BatchedRoboRugbyEnv(n, preset=args.preset, device=dev, seed=0, time_limit=True, auto_reset=True,
-                                 dtype=args.dtype, arena_offset=rrd.shard_offset(rank, n), step_budget_clocks=args.budget)
+                                 dtype=args.dtype, arena_offset=rrd.shard_offset(rank, n), step_budget_clocks=args.budget,
+                                 exact_trig=args.exact_trig)
     p = env.preset
     na = p.nr
     obs = env.reset()
@@ -367,13 +370,14 @@ def main():
                                    + (", arenas at uniformly random episode phases (pre-roll of one whole episode outside the timed region)"
                                       if stagger else ", timed right after a fresh reset")
                                    + (f", BUDGETED step ({args.budget} clocks): {n_not_ready} NOT_READY rows not counted" if args.budget else "")
+                                   + (", EXACT-TRIG parity build (double-double sin / cos)" if args.exact_trig else "")
                                    + (", fp32 FAST MODE: state and arithmetic in fp32 -- the 1e-5 parity bar holds on quiet steps only "
                                       "(contact steps: statistical, tests/test_gpu_fp32.py); fp64 is the parity mode" if args.dtype == "f32" else ""),
                        "arenas_per_gpu": n, "preset": args.preset, "policy": args.policy, "lanes_per_arena": env.lanes_per_env(),
                        "sharding": f"dp{world} (independent arena shards, returns all-gathered every "
                                    f"{gather_every} steps and once after the loop)" if world > 1 else "single GPU",
                        "steps_per_launch": F, "fault_status_bits_seen": status_bits, "staggered_phases": bool(stagger),
-                       "parity_mode": args.dtype == "f64",
+                       "parity_mode": args.dtype == "f64", "exact_trig": bool(args.exact_trig),
                        "step_budget_clocks": args.budget, "not_ready_fraction": n_not_ready / float(n * K),
                        "collectives": {"all_gather_calls": len(pending), "ranks": world, "backend": rrd.backend_name(),
                                        "bytes_per_rank": 4 * n, "gathered_rows": gathered_rows[-1] if gathered_rows else 0,
