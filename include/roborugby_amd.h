@@ -155,6 +155,14 @@ int rr_reset_to_poses(rr_env *env, const uint8_t *mask, const double *robots_xyr
 /* Episode bookkeeping for checkpoint / resume (build-side; the reference pickles the agent and never the env):
  * ints [N,5] = episode index (keys the reset RNG), steps in the running episode, finished episodes, length of the last
  * finished episode, fault flag; acc [N,4] = running return happy / grumpy, last finished return happy / grumpy. */
+/* Parity build only (rr_exact_trig() == 1; the default library returns -3): the centre of the reference's module-global scratch
+ * rect `_rectBallInner` (RR_TrashyPhysics.py:26-36), xy [N,2] fp64, device pointers.  Its centre setters are relative moves
+ * (MyUtils.py:266-275), so the centre the next ball diameter is built from depends, in the last bits, on where the previous user left
+ * it -- state that survives resets and, in a process that runs several envs, episodes.  The parity build keeps it in each arena's
+ * record; rr_set_state puts it on the last ball (where every sub-step leaves it), rr_set_scratch_rect seeds it from a dumped
+ * reference state (tests/golden/traj_*.npz `state_inner`), rr_reset / rr_set_poses leave it alone like the reference does. */
+int rr_get_scratch_rect(rr_env *env, double *xy, void *stream);
+int rr_set_scratch_rect(rr_env *env, const double *xy, void *stream);
 int rr_get_episode_state(rr_env *env, int32_t *ints, double *acc, void *stream);
 int rr_set_episode_state(rr_env *env, const int32_t *ints, const double *acc, void *stream);
 

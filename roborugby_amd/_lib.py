@@ -66,6 +66,8 @@ SYMBOLS = {
     "rr_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "rr_set_poses": (C.c_int, [_vp, _vp, _vp, _vp]),
     "rr_reset_to_poses": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rr_get_scratch_rect": (C.c_int, [_vp, _vp, _vp]),
+    "rr_set_scratch_rect": (C.c_int, [_vp, _vp, _vp]),
     "rr_get_episode_state": (C.c_int, [_vp, _vp, _vp, _vp]),
     "rr_set_episode_state": (C.c_int, [_vp, _vp, _vp, _vp]),
     "rr_episode_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),

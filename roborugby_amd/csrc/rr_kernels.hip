@@ -147,6 +147,22 @@ __global__ void k_set_state(typename C::Real *recs, int32_t *irecs, int n, const
     irec[3 * NR + 0] = step[a];
     irec[3 * NR + 5] = 0; // fault flag
     irec[3 * NR + 6] = 0; // no island carried over from the previous step (Arena::I::fzp)
+#if RR_CARRY
+    // the scratch rect where a sub-step leaves it, on the last ball (rr_set_scratch_rect overrides: a dumped reference state has its own)
+    rec[10 * NR + 8 * NB + 4] = rec[10 * NR + 0 * NB + NB - 1]; rec[10 * NR + 8 * NB + 5] = rec[10 * NR + 1 * NB + NB - 1];
+#endif
+}
+// centre of the reference's scratch rect (Arena::P::ic, parity build only): xy [N,2]
+template <class C>
+__global__ void k_scratch_rect(typename C::Real *recs, int n, double *xy, int set) {
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+#if RR_CARRY
+    typename C::Real *rec = recs + (size_t)a * Arena<C>::P_STRIDE + 10 * C::NR + 8 * C::NB + 4;
+    for (int k = 0; k < 2; k++) { if (set) rec[k] = (typename C::Real)xy[(size_t)a * 2 + k]; else xy[(size_t)a * 2 + k] = (double)rec[k]; }
+#else
+    (void)recs; (void)xy; (void)set;
+#endif
 }
 template <class C>
 __global__ void k_get_state(const typename C::Real *recs, const int32_t *irecs, int n, double *robots, int32_t *ri,
@@ -878,6 +894,22 @@ static int episode_state_impl(rr_env *e, int32_t *ints, double *acc, int set, vo
     HIP_TRY(hipGetLastError());
     return 0;
 }
+static int scratch_rect_impl(rr_env *e, double *xy, int set, void *stream) {
+    if (!e || !xy) return fail(-1, "rr_get/set_scratch_rect: null argument");
+    if (!RR_CARRY) return fail(-3, "rr_get/set_scratch_rect: only the parity build (libroborugby_amd_exact.so) carries the scratch rect");
+    const int n = e->cfg.num_envs;
+    DeviceGuard guard(e->cfg.device);
+    int rc = dispatch(e, [&](auto c) {
+        using CC = decltype(c); using RR = typename CC::Real;
+        hipLaunchKernelGGL((k_scratch_rect<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (RR *)e->recs, n, xy, set);
+        return 0;
+    });
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int rr_get_scratch_rect(rr_env *e, double *xy, void *stream) { return scratch_rect_impl(e, xy, 0, stream); }
+int rr_set_scratch_rect(rr_env *e, const double *xy, void *stream) { return scratch_rect_impl(e, const_cast<double *>(xy), 1, stream); }
 int rr_get_episode_state(rr_env *e, int32_t *ints, double *acc, void *stream) { return episode_state_impl(e, ints, acc, 0, stream); }
 int rr_set_episode_state(rr_env *e, const int32_t *ints, const double *acc, void *stream) {
     return episode_state_impl(e, const_cast<int32_t *>(ints), const_cast<double *>(acc), 1, stream);

@@ -165,6 +165,11 @@ RR_HD float m_rint(float x) { return ::rintf(x); }
 #ifndef RR_EXACT_TRIG
 #define RR_EXACT_TRIG 0
 #endif
+// The parity build also carries the centre of the reference's module-global scratch rect (_rectBallInner, RR_TrashyPhysics.py:26-36)
+// from one use to the next: see "scratch-rect carry" below.  fp64 configurations only (the fp32 mode is not a parity mode).
+#ifndef RR_CARRY
+#define RR_CARRY RR_EXACT_TRIG
+#endif
 #if RR_EXACT_TRIG
 // The "exact trig" build (libroborugby_amd_exact.so, BatchedRoboRugbyEnv(exact_trig=True)): sin & cos to ~2^-63 of their true values
 // before the one final rounding, i.e. correctly rounded except on ~1 argument in 10^4.  Why: the reference's math.sin / math.cos
@@ -412,6 +417,9 @@ template <class C> struct ArenaBody {
         R rcx[NR], rcy[NR], rl[NR], rrt[NR], rt[NR], rb[NR], rrot[NR], px[NR], py[NR], prot[NR];
         R bcx[NB], bcy[NB], bl[NB], brt[NB], bt[NB], bb[NB], bvx[NB], bvy[NB];
         R acc[4]; // running return happy/grumpy, last finished return happy/grumpy
+#if RR_CARRY
+        R ic[2];  // centre of the reference's scratch rect _rectBallInner as its last user left it ("scratch-rect carry")
+#endif
     } p;
     struct I {
         int32_t mc[NR], thl[NR], thr[NR];
@@ -429,6 +437,9 @@ template <class C> struct ArenaBody {
     int32_t bmass[NB];
     uint16_t bbm[NB], brc[NB]; // per-ball hit / close bit masks of the contact sweeps (one lane per ball writes its own; 16 bits:
                                // NB <= 11, NR <= 8 -- the G slice has no byte to spare, see wm below)
+#if RR_CARRY
+    uint16_t bcm[NB];         // per-ball mask of the robots with a corner inside the ball (the pairs that return before touching the scratch rect)
+#endif
     R exc[NB];                // how far (L1) the contact responses of this sub-step have carried the ball from its frame-begin centre
     R reach[NB];              // 14.04 + the most the ball can travel in this sub-step's roll: the ball-ball bound of the fused roll phase
     int32_t sides_ok; // sm/sc match the current robot poses (rebuilt lazily by the first phase that needs them)
@@ -819,6 +830,72 @@ template <class C> RR_HD uint32_t detect_robot_pairs(Arena<C> &A) {
     }
     return pairs;
 }
+#if RR_CARRY
+// ---- scratch-rect carry (parity build only).
+// The reference keeps ONE module-global FloatRect, _rectBallInner (RR_TrashyPhysics.py:26-36), whose corners give the ball diameters
+// parallel / perpendicular to a robot's sides.  ball_robot_collided (:53), apply_force_to_ball (:94) and bounce_ball_off_bot (:165)
+// each "move" it onto the ball with `_rectBallInner.center = ball.center`, and FloatRect's centre setters are relative moves
+// (MyUtils.py:266-275: `_move_linear(new - old)`, i.e. c <- c + (x - c)) -- so the centre the diameters are built from is
+// fl(c_old + fl(x - c_old)), which differs from x in the last bits whenever c_old is far away (a different ball), and that c_old
+// is whatever the previous user left: the rect carries state from pair to pair, sweep to sweep, step to step and (one module,
+// many envs) episode to episode.  The default build places the rect exactly on the ball -- a <= 1e-13 px difference in a diameter's
+// end points that only a free-running episode ever notices.  Here the carry is reproduced:
+//   * within one collision sweep (collision_pairs: ball-major, every robot for every ball, RR_TrashyPhysics.py:352-362) ball b's
+//     FIRST pair that reaches the setter -- its lowest robot without a corner inside the ball (:49-51 return before it) --
+//     sees c1(b) = carry(c_in(b), x_b); every later pair of the ball sees x_b exactly (x_b - c1(b) is exact by Sterbenz and so is
+//     the sum); the rect leaves ball b at x_b (>= 2 setter calls), c1(b) (one) or c_in(b) (none), which is c_in(b + 1);
+//   * c_in(0) of a sweep and the c_old of a response is A.p.ic, the centre the last user left; it lives in the arena's record
+//     (rr_set_scratch_rect / rr_get_scratch_rect seed and read it), since a reset moves the balls but not the rect.
+template <typename R> RR_HD R carry1(R c_old, R x) { return c_old + (x - c_old); }
+template <class C> RR_HD int corner_free_robots(const Arena<C> &A, int b) { return C::NR - __builtin_popcount((unsigned)A.bcm[b]); }
+// centre of the scratch rect when the sweep reaches ball `upto` (= what ball upto - 1 left behind); bcm[] must be current
+template <class C> RR_HD V2<typename C::Real> carry_chain(const Arena<C> &A, int upto) {
+    using R = typename C::Real;
+    V2<R> c = { A.p.ic[0], A.p.ic[1] };
+    for (int b = 0; b < upto; b++) {
+        const int nset = corner_free_robots(A, b);
+        const V2<R> c1 = { carry1<R>(c.x, A.p.bcx[b]), carry1<R>(c.y, A.p.bcy[b]) };
+        if (nset >= 2) { c.x = A.p.bcx[b]; c.y = A.p.bcy[b]; }
+        else if (nset == 1) c = c1;
+    }
+    return c;
+}
+// the centre pair (b, r) builds its diameters from
+template <class C> RR_HD V2<typename C::Real> carry_centre(const Arena<C> &A, int b, int r) {
+    using R = typename C::Real;
+    const unsigned cm = A.bcm[b], low = (1u << r) - 1u;
+    V2<R> x = { A.p.bcx[b], A.p.bcy[b] };
+    if ((cm & low) != low) return x; // a lower robot already moved the rect onto this ball
+    const V2<R> c = carry_chain(A, b);
+    V2<R> c1 = { carry1<R>(c.x, x.x), carry1<R>(c.y, x.y) };
+    return c1;
+}
+// a sweep in which no ball is near any robot (the two the fast path of a sub-step skips, RR_EnvBase.py:335 and :372): every pair
+// reaches the setter
+template <class C> RR_HD void carry_quiet_sweep(Arena<C> &A) {
+    V2<typename C::Real> c = { A.p.bcx[C::NB - 1], A.p.bcy[C::NB - 1] }; // two or more robots: the last ball's later pairs put it there exactly
+    if constexpr (C::NR < 2) {
+        RR_FOR_LANES(l) { if (l < C::NB) A.bcm[l] = 0; }
+        RR_SYNC();
+        c = carry_chain(A, C::NB);
+    }
+    RR_SYNC();
+    if (RR_IS_LANE0) { A.p.ic[0] = c.x; A.p.ic[1] = c.y; }
+    RR_SYNC();
+}
+// the balls outside an island `kb` whose position the island's sweeps and responses depend on through the scratch rect
+template <class C> RR_HD uint32_t carry_deps(uint32_t kb) { return kb ? (((kb >> 1) | (1u << (C::NB - 1))) & ~kb) : 0u; }
+// a response's setter call (apply_force_to_ball / bounce_ball_off_bot): returns the centre its diameters are built from
+template <class C> RR_HD V2<typename C::Real> carry_response(Arena<C> &A, V2<typename C::Real> bc) {
+    using R = typename C::Real;
+    const V2<R> c = { carry1<R>(A.p.ic[0], bc.x), carry1<R>(A.p.ic[1], bc.y) };
+    RR_TRACE("E scratch rect (%.17g,%.17g) -> (%.17g,%.17g) for ball at (%.17g,%.17g)\n", (double)A.p.ic[0], (double)A.p.ic[1], (double)c.x, (double)c.y, (double)bc.x, (double)bc.y);
+    RR_SYNC();
+    if (RR_IS_LANE0) { A.p.ic[0] = c.x; A.p.ic[1] = c.y; }
+    RR_SYNC();
+    return c;
+}
+#endif
 // ball_robot_collided (RR_TrashyPhysics.py:39-69): task = (ball, robot, diameter); each lane tests two
 // corners against the radius and its diameter against the four sides.  Bit (b*NR + r) of the result.
 // CACHED = false (the first sweep of a sub-step, usually the only one): a lane computes everything it needs itself --
@@ -835,13 +912,40 @@ template <class C, bool CACHED> RR_HD uint32_t detect_ball_robot(Arena<C> &A, co
         bool c = false;
         if (l < C::NB) {
             int msk = 0;
+#if RR_CARRY
+            int cmk = 0;
+            const V2<R> xb = { A.p.bcx[l], A.p.bcy[l] };
+            for (int r = 0; r < C::NR; r++) {
+                const bool near = ball_near_robot(A, l, r);
+                msk |= near ? (1 << r) : 0;
+                if (near) { // the corner tests that make ball_robot_collided return before it touches the scratch rect (:49-51)
+                    bool ch = false;
+                    for (int k = 0; k < 4; k++) ch = ch | (dist<R>(robot_corner(A, r, k), xb) < (R)7);
+                    cmk |= ch ? (1 << r) : 0;
+                }
+            }
+            A.bcm[l] = (uint16_t)cmk;
+#else
             for (int r = 0; r < C::NR; r++) msk |= ball_near_robot(A, l, r) ? (1 << r) : 0;
+#endif
             A.brc[l] = (uint16_t)msk;
             c = msk != 0;
         }
         RR_VOTE(anyc, l, c);
     }
+#if RR_CARRY
+    // where this sweep leaves the scratch rect; written once every lane has built its diameters from the centre it found
+    auto carry_done = [&]() {
+        RR_SYNC();
+        const V2<R> cend = carry_chain(A, C::NB);
+        RR_SYNC();
+        if (RR_IS_LANE0) { A.p.ic[0] = cend.x; A.p.ic[1] = cend.y; }
+        RR_SYNC();
+    };
+    if (!RR_UNLIKELY(anyc)) { carry_done(); return 0; }
+#else
     if (!RR_UNLIKELY(anyc)) return 0;
+#endif
     if (CACHED) RR_STAMP(26);
     RR_SYNC();
     uint32_t close = 0;
@@ -884,7 +988,12 @@ template <class C, bool CACHED> RR_HD uint32_t detect_ball_robot(Arena<C> &A, co
                         corners_for<R>(norm360<R>(A.p.rrot[r] + (R)45), sp.inner_h, sp.inner_h, sp.inner_cdist, iq);
                         ox = d == 0 ? iq[0] : iq[2]; oy = d == 0 ? iq[1] : iq[3];
                     }
-                    Seg<R> dia = { { bc.x + ox, bc.y + oy }, { bc.x + -ox, bc.y + -oy } };
+#if RR_CARRY
+                    const V2<R> dc = carry_centre(A, b, r);
+#else
+                    const V2<R> dc = bc;
+#endif
+                    Seg<R> dia = { { dc.x + ox, dc.y + oy }, { dc.x + -ox, dc.y + -oy } };
                     Seg<R> side = robot_side(A, r, sd);
                     R md, cd, ms, cs;
                     slope_yint<R>(dia.a, dia.b, md, cd, st);
@@ -920,7 +1029,12 @@ template <class C, bool CACHED> RR_HD uint32_t detect_ball_robot(Arena<C> &A, co
                     corners_for<R>(norm360<R>(A.p.rrot[r] + (R)45), sp.inner_h, sp.inner_h, sp.inner_cdist, iq);
                     ox = d == 0 ? iq[0] : iq[2]; oy = d == 0 ? iq[1] : iq[3];
                 }
-                Seg<R> dia = { { bc.x + ox, bc.y + oy }, { bc.x + -ox, bc.y + -oy } };
+#if RR_CARRY
+                const V2<R> dc = carry_centre(A, b, r);
+#else
+                const V2<R> dc = bc;
+#endif
+                Seg<R> dia = { { dc.x + ox, dc.y + oy }, { dc.x + -ox, dc.y + -oy } };
                 bool need[4], any_need = false;
                 for (int sd = 0; sd < 4; sd++) { need[sd] = boxes_meet<R>(robot_side(A, r, sd), dia, (R)0); any_need = any_need | need[sd]; }
                 if (any_need) {
@@ -946,6 +1060,9 @@ template <class C, bool CACHED> RR_HD uint32_t detect_ball_robot(Arena<C> &A, co
     }
     }
     if (CACHED) RR_STAMP(28);
+#if RR_CARRY
+    carry_done();
+#endif
     if (pairs && !CACHED) { // rare: the responses read the cached inner-square offsets and side slopes
         RR_FOR_LANES(l) {
             if (l < C::NR) refresh_inner_lane(A, sp, l);
@@ -1161,7 +1278,11 @@ template <class C> RR_HDN void apply_force_to_ball(Arena<C> &A, const SimParams<
     const R cbuf = (R).5;
     V2<R> bc = { A.p.bcx[b], A.p.bcy[b] }, rc = { A.p.rcx[r], A.p.rcy[r] };
     Seg<R> dia[2];
+#if RR_CARRY
+    force_diameters(A, r, carry_response(A, bc), dia); // `_rectBallInner.center = spr_ball.rectDbl.center` (:94), a relative move
+#else
     force_diameters(A, r, bc, dia);
+#endif
     R fx = A.bfx[b], fy = A.bfy[b];
     bool done = false;
     const int k = kpre != -2 ? kpre : first_surface_hit(A, r, dia, cbuf);
@@ -1215,7 +1336,11 @@ template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, const SimParams<
     const R cbuf = (R).5;
     V2<R> bc = { A.p.bcx[b], A.p.bcy[b] };
     Seg<R> dia[2];
+#if RR_CARRY
+    force_diameters(A, r, carry_response(A, bc), dia); // (:165)
+#else
     force_diameters(A, r, bc, dia);
+#endif
     R mvx = 0, mvy = 0;
     bool done = false;
     RR_T0();
@@ -1583,6 +1708,11 @@ RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, co
                 A.bmass[l] = 1; A.bfx[l] = (R)0; A.bfy[l] = (R)0; A.exc[l] = (R)0;
                 A.pfx[l] = ball_copy_c<R>(A.p.bcx[l]); A.pfy[l] = ball_copy_c<R>(A.p.bcy[l]);
                 A.reach[l] = (R)14.04 + ((m_abs(A.p.bvx[l]) + m_abs(A.p.bvy[l])) * (R)1.01 + (R)0.02);
+#if RR_CARRY
+                // the frozen island's sweeps found the scratch rect where the ball before each of its balls (and the last ball, via
+                // A.p.ic) had left it: such a ball outside the island has to stand still, or the island is thawed
+                if (FZ && ((carry_deps<C>(fz.b) >> l) & 1u)) c_br = c_br | (A.p.bvx[l] != (R)0) | (A.p.bvy[l] != (R)0);
+#endif
                 for (int r2 = 0; r2 < C::NR; r2++) { // ball-robot: 22.36 + 9.9 (+ 3 px of robot motion)
                     R dx = A.p.bcx[l] - A.p.rcx[r2], dy = A.p.bcy[l] - A.p.rcy[r2];
                     bool cl = dx * dx + dy * dy <= (R)(36.0 * 36.0);
@@ -1677,6 +1807,9 @@ RR_HD void push_balls(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32
         const int p = low_bit(todo);
         hit.b |= 1u << (p / C::NR); hit.r |= 1u << (p % C::NR);
         int kf, kb;
+#if RR_CARRY
+        kf = kb = -2; // the two responses may see the scratch rect at centres one ulp apart: each runs its own search
+#else
         {
             using R = typename C::Real;
             const int r = p % C::NR, b = p / C::NR;
@@ -1685,6 +1818,7 @@ RR_HD void push_balls(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32
             force_diameters(A, r, bc, dia);
             first_surface_hit2(A, r, dia, (R).5, (R)0, kf, kb);
         }
+#endif
         apply_force_to_ball(A, sp, p % C::NR, p / C::NR, bots_moved, st, kf);
         RR_STAMP(20);
         bounce_ball_off_bot(A, sp, p % C::NR, p / C::NR, bots_moved, st, kb);
@@ -1781,6 +1915,9 @@ RR_HD bool substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
         RR_TRACE("E push mask %08x\n", br);
         push_balls(A, sp, br, bots_moved, st, hit);
     }
+#if RR_CARRY
+    else carry_quiet_sweep(A); // the push sweep the fast path skips still walks the scratch rect over every ball
+#endif
     RR_STAMP(3);
     // phase 2: _roll_balls AND the fused first pass of _resolve_ball_collisions: anything possibly touching?  Ball-ball
     // runs in the same phase as the roll, so the other ball may be seen before or after its own roll: the bound (A.reach,
@@ -1804,6 +1941,9 @@ RR_HD bool substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
         RR_SYNC();
     }
     RR_TRACE("E phase2 any %d\n", (int)(m_any != 0));
+#if RR_CARRY
+    if (!m_any) carry_quiet_sweep(A); // ... and so does the one pass of the resolve loop
+#endif
     } // !reentry
     if (RR_UNLIKELY(m_any)) { // the reference's loop, from its first pass (nothing has changed since the broad phase above)
         int count_now = 0;
@@ -2279,6 +2419,9 @@ RR_HD void snapshot_compare_update(const Arena<C> &A, uint32_t *snap, int32_t *i
                     const int fld = idx / C::NR; // rcx rcy | rl rrt rt rb | rrot px py prot
                     mine |= d ? (1u << (idx % C::NR + ((fld >= 2 && fld <= 5) ? C::NR : 0))) : 0u;
                 } else if (idx < 10 * C::NR + 8 * C::NB) mine |= d ? (1u << (2 * C::NR + (idx - 10 * C::NR) % C::NB)) : 0u;
+#if RR_CARRY
+                else if (idx >= 10 * C::NR + 8 * C::NB + 4) mine |= d ? (1u << (2 * C::NR + C::NB - 1)) : 0u; // the scratch rect sits on the last ball
+#endif
             } else {
                 axd = axd | d;
             }
@@ -2542,8 +2685,11 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
             snapshot_compare_update(A, o.snap(), o.isnap(), have, chg_r, chg_re, chg_b, ax_diff);
             RR_TRACE("E snapshot at %d: have %d chg_r %x edges %x chg_b %x hit r %x b %x moved %x/%x work %d\n", f, (int)have, chg_r, chg_re, chg_b, hit.r, hit.b, prev_moved, snap_moved, work);
             if (have) {
-                const bool island_ok = (hit.r | hit.b) && !(chg_r & hit.r) && !(chg_b & hit.b) && !((prev_moved | snap_moved) & hit.r) &&
-                                       !robots_clamped(A, hit.r);
+                bool island_ok = (hit.r | hit.b) && !(chg_r & hit.r) && !(chg_b & hit.b) && !((prev_moved | snap_moved) & hit.r) &&
+                                 !robots_clamped(A, hit.r);
+#if RR_CARRY
+                island_ok = island_ok && !(carry_deps<C>(hit.b) & chg_b); // (see substep_phase1: the balls the island's scratch-rect chain starts from)
+#endif
                 if (!(chg_r | chg_re | chg_b) && !ax_diff && snap_moved == prev_moved) {
                     RR_TRACE("E fixed point after sub-step %d\n", f);
                     if (FZP && island_ok) { fz = hit; fz_bits = fz_pack_bits(n_sub, st_sub); } // for the NEXT step (this one is done)

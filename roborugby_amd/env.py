@@ -396,6 +396,18 @@ class BatchedRoboRugbyEnv:
                    "rr_get_state")
         return dict(robots=robots, robots_i=robots_i, balls=balls, step=step)
 
+    def set_scratch_rect(self, xy):
+        """Parity build only (exact_trig=True): centre of the reference's module-global scratch rect, [N,2] fp64 -- e.g. the
+        `state_inner[..., :2]` a golden trajectory dumped (include/roborugby_amd.h: rr_set_scratch_rect)."""
+        xy = torch.as_tensor(xy, dtype=torch.float64, device=self.device).contiguous().view(self.num_envs, 2)
+        _lib.check(self._lib.rr_set_scratch_rect(self._h, _ptr(xy), self._stream()), "rr_set_scratch_rect")
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def get_scratch_rect(self):
+        xy = self._new((self.num_envs, 2), torch.float64)
+        _lib.check(self._lib.rr_get_scratch_rect(self._h, _ptr(xy), self._stream()), "rr_get_scratch_rect")
+        return xy
+
     def get_episode_state(self):
         """Build-side bookkeeping that a checkpoint has to carry next to get_state(): `ints` [N,5] = episode index (keys the
         reset RNG: without it a resumed run would replay the placements of episodes 1, 2, ...), steps in the running

@@ -62,6 +62,9 @@ template <class C> static void set_state(Emu<C> *e, const double *robots, const 
     A.i.step = step;
     A.i.fault = 0;
     A.i.fzp = 0;
+#if RR_CARRY
+    A.p.ic[0] = A.p.bcx[C::NB - 1]; A.p.ic[1] = A.p.bcy[C::NB - 1]; // where a sub-step leaves the scratch rect (emu_set_scratch_rect overrides)
+#endif
     derive(A, e->sp);
 }
 template <class C> static void get_state(Emu<C> *e, double *robots, int32_t *ri, double *balls, int32_t *step) {
@@ -150,6 +153,25 @@ void emu_set_state(Handle *h, const double *robots, const int32_t *ri, const dou
 }
 void emu_get_state(Handle *h, double *robots, int32_t *ri, double *balls, int32_t *step) {
     DISPATCH(h, get_state<CC>(e, robots, ri, balls, step));
+}
+// centre of the reference's scratch rect (_rectBallInner): 1 if this build carries it (the parity build), 0 otherwise
+int emu_set_scratch_rect(Handle *h, const double *xy) {
+#if RR_CARRY
+    DISPATCH(h, e->A.p.ic[0] = (typename CC::Real)xy[0]; e->A.p.ic[1] = (typename CC::Real)xy[1]);
+    return 1;
+#else
+    (void)h; (void)xy;
+    return 0;
+#endif
+}
+int emu_get_scratch_rect(Handle *h, double *xy) {
+#if RR_CARRY
+    DISPATCH(h, xy[0] = (double)e->A.p.ic[0]; xy[1] = (double)e->A.p.ic[1]);
+    return 1;
+#else
+    (void)h; (void)xy;
+    return 0;
+#endif
 }
 void emu_set_poses(Handle *h, const double *rxyr, const double *bxyv) {
     DISPATCH(h, for (int r = 0; r < CC::NR; r++) robot_set_clean_lane(e->A, e->sp, r, (typename CC::Real)rxyr[3 * r],

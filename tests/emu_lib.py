@@ -28,7 +28,13 @@ _lib = None
 _libs = {}
 
 
-def lib(exact=False):
+# RR_EMU_EXACT=1: every test that does not say otherwise runs against the parity build (tests/test_parity_build.py re-runs the
+# shortcut-equivalence suites that way)
+DEFAULT_EXACT = bool(int(os.environ.get("RR_EMU_EXACT", "0")))
+
+
+def lib(exact=None):
+    exact = DEFAULT_EXACT if exact is None else exact
     global _lib
     if exact:
         if True not in _libs:
@@ -47,6 +53,8 @@ def _bind(L):
     L.emu_set_state.argtypes = [C.c_void_p, dp, ip, dp, C.c_int]
     L.emu_get_state.argtypes = [C.c_void_p, dp, ip, dp, ip]
     L.emu_set_poses.argtypes = [C.c_void_p, dp, dp]
+    L.emu_set_scratch_rect.argtypes = [C.c_void_p, dp]
+    L.emu_get_scratch_rect.argtypes = [C.c_void_p, dp]
     L.emu_step.argtypes = [C.c_void_p, ip, C.c_int, dp, dp, dp, dp, u8p]
     L.emu_step_budget.argtypes = [C.c_void_p, ip, C.c_int, dp, dp, dp, dp, u8p, C.c_int]
     L.emu_park_seed.argtypes = [C.c_void_p, C.c_uint32]
@@ -72,8 +80,8 @@ def _ip(a):
 
 
 class EmuEnv:
-    def __init__(self, preset="T", f32=False, time_limit=0, auto_reset=0, seed=0, narrow=False, reset_on_fault=0, exact=False):
-        self._exact = bool(exact)
+    def __init__(self, preset="T", f32=False, time_limit=0, auto_reset=0, seed=0, narrow=False, reset_on_fault=0, exact=None):
+        self._exact = DEFAULT_EXACT if exact is None else bool(exact)
         cfg = ol.PRESETS[preset]
         self.cfg = cfg
         self.nr = cfg["nr_h"] + cfg["nr_g"]
@@ -92,6 +100,15 @@ class EmuEnv:
         ri = np.ascontiguousarray(robots_i, np.int32)
         b = np.ascontiguousarray(balls, np.float64)
         lib(self._exact).emu_set_state(self.h, _dp(r), _ip(ri), _dp(b), int(step))
+
+    def set_scratch_rect(self, xy):
+        """centre of the reference's scratch rect (golden `state_inner[..., :2]`); False if the build does not carry it"""
+        v = np.ascontiguousarray(np.asarray(xy, np.float64)[:2])
+        return bool(lib(self._exact).emu_set_scratch_rect(self.h, _dp(v)))
+
+    def get_scratch_rect(self):
+        v = np.zeros(2)
+        return v if lib(self._exact).emu_get_scratch_rect(self.h, _dp(v)) else None
 
     def get_state(self):
         r = np.zeros((self.nr, 10))

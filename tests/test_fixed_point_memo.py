@@ -109,7 +109,8 @@ def test_island_freeze_exact_on_stuck_islands_from_a_rollout_G(fixture):
         c = _count_events(lambda: _rollout("G", None, None, d["actions"][a], True, 3, state=state), tuple(fired))
         for k in fired:
             fired[k] += c[k]
-    assert fired["freeze"] >= 20, fired
+    # (the parity build also wants the balls its scratch-rect chain starts from to stand still: fewer islands qualify)
+    assert fired["freeze"] >= (12 if el.DEFAULT_EXACT else 20), fired
 
 
 def test_island_thaw_paths_are_exact_G():
@@ -145,7 +146,7 @@ def test_island_thaw_paths_are_exact_G():
         c = _count_events(lambda: _rollout("G", None, None, act, True, 2, state=state), tuple(fired))
         for k in fired:
             fired[k] += c[k]
-    assert fired["freeze"] > 100 and fired["thaw in phase 1"] > 50 and fired["thaw in phase 2"] > 10, fired
+    assert fired["freeze"] > 100 and fired["thaw in phase 1"] > (20 if el.DEFAULT_EXACT else 50) and fired["thaw in phase 2"] > 10, fired
 
 
 def _rollout_seq(preset, state, acts, memo, poke=None):

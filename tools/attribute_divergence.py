@@ -42,6 +42,8 @@ def free_run(make_env, t, ep, na):
     """first step index whose post-state differs from the golden (None: tracks to the end)"""
     env = make_env()
     env.set_state(t["state_robots"][ep, 0], t["state_robots_i"][ep, 0], t["state_balls"][ep, 0], *( [t["state_inner"][ep, 0]] if hasattr(env, "nr") and isinstance(env, ol.OracleEnv) else []), step=int(t["state_step"][ep, 0]))
+    if hasattr(env, "set_scratch_rect"):
+        env.set_scratch_rect(t["state_inner"][ep, 0])
     L = int(t["length"][ep])
     for s in range(L):
         a = np.clip(t["actions"][ep, s, :na], 0, 7).astype(np.int32)

@@ -1,11 +1,11 @@
 #!/bin/bash
-# r03: the exact-trig parity build on the GPU -- parity tests with both libraries, then its cost on the bench line
+# r03: the parity build (exact trig + scratch-rect carry) on the GPU -- parity tests with both libraries, then its cost on the bench line
 TAG=${1:-r03_exact}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -p no:cacheprovider > $OUT/pytest.log 2>&1
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_memo.py -m gpu -q -s -p no:cacheprovider > $OUT/pytest.log 2>&1
 rc=$?
 tail -n 25 $OUT/pytest.log
 if [ $rc -ge 124 ]; then echo "pytest hung or was killed: no further GPU step"; exit $rc; fi
