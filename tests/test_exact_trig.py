@@ -42,21 +42,7 @@ def test_exact_sincos_is_correctly_rounded_and_agrees_with_glibc():
     assert np.abs(got - cr).max() < 2.3e-16
 
 
-@pytest.mark.parametrize("preset,want", [("T", 13), ("G", 3), ("D", 4)])
-def test_exact_trig_follows_whole_golden_episodes_bit_for_bit(golden_dir, preset, want):
-    t = dict(np.load(f"{golden_dir}/traj_{preset}.npz"))
-    t["_preset"] = preset
-    na_used = (t["actions"][:, 0, :] >= 0).sum(1)
-    full = np.nonzero(na_used == na_used.max())[0]
-    na = int(na_used.max())
-    fast = [ad.free_run(lambda: el.EmuEnv(preset), t, ep, na) for ep in full]
-    exact = [ad.free_run(lambda: el.EmuEnv(preset, exact=True), t, ep, na) for ep in full]
-    n_fast, n_exact = sum(x is None for x in fast), sum(x is None for x in exact)
-    print(f"[{preset}] free-running golden episodes bit-identical to the reference to their last step: default build {n_fast}, exact-trig build "
-          f"{n_exact} of {len(full)}; first departures (exact): {[x for x in exact if x is not None]}")
-    assert n_exact >= want and n_exact > n_fast
-    later = sum(1 for a, b in zip(fast, exact) if a is not None and (b is None or b >= a))
-    assert later >= sum(a is not None for a in fast) - 1  # (an episode may leave a little earlier by chance; not the rule)
+# (whole free-running golden episodes, bit for bit: tests/test_parity_build.py -- the parity build also carries the scratch rect)
 
 
 @pytest.mark.parametrize("preset", ["T", "G"])

@@ -14,12 +14,15 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _env(n, preset, **env_vars):
+BUILDS = pytest.mark.parametrize("exact", [False, True], ids=["default", "parity_build"])  # the parity build's carry has to survive the shortcuts too
+
+
+def _env(n, preset, exact=False, **env_vars):
     import roborugby_amd as rr
     old = {k: os.environ.get(k) for k in env_vars}
     os.environ.update({k: str(v) for k, v in env_vars.items()})
     try:
-        return rr.BatchedRoboRugbyEnv(n, preset=preset, seed=3, time_limit=False, auto_reset=False)  # switches are read at creation
+        return rr.BatchedRoboRugbyEnv(n, preset=preset, seed=3, time_limit=False, auto_reset=False, exact_trig=exact)  # switches are read at creation
     finally:
         for k, v in old.items():
             if v is None:
@@ -43,7 +46,8 @@ def _same(a, b):
     return all(np.array_equal(x, y, equal_nan=True) for sa, sb in zip(a, b) for x, y in zip(sa, sb))
 
 
-def test_stuck_islands_shortcuts_off_equals_on_and_match_oracle():
+@BUILDS
+def test_stuck_islands_shortcuts_off_equals_on_and_match_oracle(exact):
     d = np.load(os.path.join(HERE, "data", "stuck_islands_G.npz"))
     f = np.load(os.path.join(HERE, "..", "tools", "fixtures", "squeezed_G.npz"))
     robots = np.concatenate([d["robots"], f["robots"][None]]); robots_i = np.concatenate([d["robots_i"], f["robots_i"][None]])
@@ -51,8 +55,8 @@ def test_stuck_islands_shortcuts_off_equals_on_and_match_oracle():
     acts = np.concatenate([d["actions"], f["actions"][None]]).astype(np.int32)
     n = len(step)
     a_t = torch.as_tensor(acts, device="cuda")
-    on = _run(_env(n, "G"), (robots, robots_i, balls, step), a_t, 4)
-    off = _run(_env(n, "G", RR_NO_MEMO=1, RR_NO_ORDER=1), (robots, robots_i, balls, step), a_t, 4)
+    on = _run(_env(n, "G", exact), (robots, robots_i, balls, step), a_t, 4)
+    off = _run(_env(n, "G", exact, RR_NO_MEMO=1, RR_NO_ORDER=1), (robots, robots_i, balls, step), a_t, 4)
     assert _same(on, off)
     # first step against the oracle (fp64, same tolerance as the parity tests)
     worst = 0.0
@@ -69,14 +73,15 @@ def test_stuck_islands_shortcuts_off_equals_on_and_match_oracle():
     assert worst < 1e-9, worst
 
 
+@BUILDS
 @pytest.mark.parametrize("preset", ["T", "G"])
-def test_contact_dense_states_shortcuts_off_equals_on(preset):
+def test_contact_dense_states_shortcuts_off_equals_on(preset, exact):
     n = 1536
     robots, balls, actions = adv.make_states(preset, n, seed=21)
     import roborugby_amd as rr
     outs = []
     for sw in ({}, {"RR_NO_MEMO": 1, "RR_NO_ORDER": 1}):
-        env = _env(n, preset, **sw)
+        env = _env(n, preset, exact, **sw)
         env.set_poses(robots, balls)
         a_t = torch.as_tensor(actions, device="cuda")
         res = []
@@ -174,8 +179,9 @@ def test_step_can_be_captured_into_a_hip_graph():
         assert torch.equal(out[0], o) and torch.equal(out[1], r) and torch.equal(out[2].bool(), d) and torch.equal(out[5], info.status), s
 
 
+@BUILDS
 @pytest.mark.parametrize("preset", ["T", "G"])
-def test_islands_carried_across_steps_shortcuts_off_equals_on(preset):
+def test_islands_carried_across_steps_shortcuts_off_equals_on(preset, exact):
     """Stuck arenas from the slowest wavefronts of a chase-policy rollout (tests/data/stuck_chase_*.npz): ten steps in which
     every robot keeps its action most of the time (the frozen island is carried into the next step), changes it now and then
     (recomputed), with one rr_set_state of the state they have in between (nothing may be carried) -- shortcuts on == off."""
@@ -190,7 +196,7 @@ def test_islands_carried_across_steps_shortcuts_off_equals_on(preset):
         acts.append(torch.as_tensor(a.astype(np.int32), device="cuda"))
     outs = []
     for sw in ({}, {"RR_NO_MEMO": 1, "RR_NO_ORDER": 1}):
-        env = _env(n, preset, **sw)
+        env = _env(n, preset, exact, **sw)
         env.set_state(d["robots"], d["robots_i"], d["balls"], d["step"].astype(np.int32))
         res = []
         for s in range(10):

@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """Which arithmetic difference makes the kernel leave the reference's trajectory, and where.
 
-The HIP kernel differs from the reference in exactly two places: its own sin/cos (< 1 ulp from glibc's) and the centre of the
+The default HIP kernel differs from the reference in exactly two places: its own sin/cos (< 1 ulp from glibc's) and the centre of the
 module-global scratch rect `_rectBallInner` (RR_TrashyPhysics.py:54,94,165: carried as c_old + (c_new - c_old); the kernel uses
-the ball centre).  The CPU oracle is bit-exact to the reference's golden episodes; with `rro_debug_attribution` it makes either
+the ball centre).  (x ** 2 / x ** .5 are x * x / sqrt(x) in the kernel and glibc's pow in the reference: correctly rounded against
+< 1 ulp, the rarest of the three.)  The PARITY build (-DRR_EXACT_TRIG=1: double-double sin/cos + the carry) removes both: its column
+shows what is left -- glibc's own roundings -- and the last line runs it against the oracle with a correctly rounded libm.  The CPU oracle is bit-exact to the reference's golden episodes; with `rro_debug_attribution` it makes either
 substitution (or both), so free-running every golden episode under each variant shows which one causes the first departure:
 
   variant 0 = reference arithmetic (must track every episode to its end, bit for bit)
   variant 1 = scratch-rect centre := ball centre        variant 2 = the kernel's sin/cos        variant 3 = both
   kernel    = the kernel's own phase source (host-emulated wave; on the GPU only atan -- observations, never state -- differs)
+  parity    = the same source built as the parity build, scratch rect seeded from the golden `state_inner`
 
 For the first step where ANY state bit differs from the golden, the sub-step is bisected (both sides run k = 1..12 sub-steps
 from the golden pre-step state) and the size of the difference is reported in ulps of the value.  No GPU.
-usage: python tools/attribute_divergence.py [T|G|both] > profiles/r03/divergence_attribution.txt"""
+usage: python tools/attribute_divergence.py [T|G|D|all] > profiles/r03/divergence_attribution.txt"""
 import os
 import sys
 
@@ -94,17 +97,44 @@ def bisect_substep(flags, t, ep, s, na, kernel=False):
     return None
 
 
+def cr_libm_agreement(preset, t, full, na):
+    """parity build and oracle (rro_debug_attribution(4)) side by side from each episode's step-0 state, compared after every step"""
+    same = 0
+    for ep in full:
+        ol.lib().rro_debug_attribution(4)
+        try:
+            o = ol.OracleEnv(preset)
+            o.set_state(t["state_robots"][ep, 0], t["state_robots_i"][ep, 0], t["state_balls"][ep, 0], t["state_inner"][ep, 0], int(t["state_step"][ep, 0]))
+            e = el.EmuEnv(preset, exact=True)
+            e.set_state(t["state_robots"][ep, 0], t["state_robots_i"][ep, 0], t["state_balls"][ep, 0], step=int(t["state_step"][ep, 0]))
+            e.set_scratch_rect(t["state_inner"][ep, 0])
+            ok = True
+            for s in range(int(t["length"][ep])):
+                a = np.clip(t["actions"][ep, s, :na], 0, 7).astype(np.int32)
+                o.step(a)
+                e.step(a)
+                so, se = o.get_state(), e.get_state()
+                if not (np.array_equal(so["robots"], se["robots"], equal_nan=True) and np.array_equal(so["balls"], se["balls"])):
+                    ok = False
+                    break
+            same += ok
+        finally:
+            ol.lib().rro_debug_attribution(0)
+    return f"{same} of {len(full)}"
+
+
 def main():
-    which = sys.argv[1] if len(sys.argv) > 1 else "both"
-    for preset in (("T", "G") if which == "both" else (which,)):
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    for preset in (("T", "G", "D") if which in ("both", "all") else (which,)):
         t = dict(np.load(os.path.join(ROOT, "tests", "golden", f"traj_{preset}.npz"), allow_pickle=False))
         t["_preset"] = preset
         na_used = (t["actions"][:, 0, :] >= 0).sum(1)
         full = np.nonzero(na_used == na_used.max())[0]
         na = int(na_used.max())
         print(f"== preset {preset}: {len(full)} free-running golden episodes (every robot driven), first step whose state differs from the reference's")
-        print(f"{'episode':>7} {'length':>6} | {'ref-arith':>9} {'no-carry':>9} {'k-sincos':>9} {'both':>9} {'kernel':>9} | first cause, sub-step, where, size")
+        print(f"{'episode':>7} {'length':>6} | {'ref-arith':>9} {'no-carry':>9} {'k-sincos':>9} {'both':>9} {'kernel':>9} {'parity':>9} | first cause, sub-step, where, size")
         tally = {"sincos": 0, "carry": 0, "none": 0}
+        parity_left = []
         for ep in full:
             res = []
             for flags in (0, 1, 2, 3):
@@ -113,7 +143,9 @@ def main():
                     res.append(free_run(lambda: ol.OracleEnv(preset), t, ep, na))
                 finally:
                     ol.lib().rro_debug_attribution(0)
-            res.append(free_run(lambda: el.EmuEnv(preset), t, ep, na))
+            res.append(free_run(lambda: el.EmuEnv(preset, exact=False), t, ep, na))
+            res.append(free_run(lambda: el.EmuEnv(preset, exact=True), t, ep, na))
+            parity_left.append(res[5])
             assert res[0] is None, f"the reference arithmetic itself leaves golden episode {ep} at step {res[0]}"
             L = int(t["length"][ep])
             f = lambda x: "-" if x is None else str(x)
@@ -131,8 +163,10 @@ def main():
                     cause += f" | kernel: step {res[4]} sub-step {bk[0]}, {bk[2]}, {bk[1]:.1f} ulp ({bk[3]:.2e})"
             else:
                 tally["none"] += 1
-            print(f"{ep:>7} {L:>6} | {f(res[0]):>9} {f(res[1]):>9} {f(res[2]):>9} {f(res[3]):>9} {f(res[4]):>9} | {cause}")
+            print(f"{ep:>7} {L:>6} | {f(res[0]):>9} {f(res[1]):>9} {f(res[2]):>9} {f(res[3]):>9} {f(res[4]):>9} {f(res[5]):>9} | {cause}")
         print(f"   first cause of the kernel's bit-level departures: {tally}")
+        print(f"   parity build: {sum(x is None for x in parity_left)} of {len(parity_left)} episodes bit-identical to the reference (glibc) to their last step; "
+              f"against the oracle with a correctly rounded libm (binary128 sin / cos, x * x, sqrt): {cr_libm_agreement(preset, t, full, na)}")
         print("   ('-' = tracks the reference bit for bit to the last step; a bit-level departure is not yet a 1e-9 departure:")
         print("    the GPU test counts episodes whose observations stay within 1e-9, tests/test_gpu_parity.py)")
 

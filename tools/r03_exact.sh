@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_memo.py -m gpu -q -s -p no:cacheprovider > $OUT/pytest.log 2>&1
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_shortcuts.py -m gpu -q -s -p no:cacheprovider > $OUT/pytest.log 2>&1
 rc=$?
 tail -n 25 $OUT/pytest.log
 if [ $rc -ge 124 ]; then echo "pytest hung or was killed: no further GPU step"; exit $rc; fi
