@@ -118,8 +118,9 @@ class BatchedRoboRugbyEnv:
         # auto-reset re-places the arena; default: on exactly when auto_reset is
         self.reset_on_fault = bool(auto_reset if reset_on_fault is None else reset_on_fault)
         p = self.preset
-        # exact_trig=True: the exact-trig parity build (libroborugby_amd_exact.so, same ABI): sin / cos of the robot kinematics ~correctly
-        # rounded, so free-running episodes follow the reference bit for bit far longer; slower, fp64 only
+        # exact_trig=True: the parity build (libroborugby_amd_exact.so, same ABI): sin / cos of the robot kinematics ~correctly rounded and
+        # the reference's scratch-rect carry (set_scratch_rect), so free-running episodes follow the reference bit for bit -- most of them
+        # to their last step; ~80 % of the default library's speed, fp64 only
         self.exact_trig = bool(exact_trig)
         if self.exact_trig and dtype != "f64":
             raise ValueError("exact_trig is a property of the fp64 parity mode")
