@@ -170,6 +170,12 @@ RR_HD float m_rint(float x) { return ::rintf(x); }
 #ifndef RR_CARRY
 #define RR_CARRY RR_EXACT_TRIG
 #endif
+// phase 1's broad tests: after the radius bounds, also the separating-axis / robot-frame bounds (with the motion slack), so that fewer
+// wavefronts enter the reference-shaped loops for pairs that merely pass each other.  A/B only: G -4 %, T -1 % (the extra tests
+// cost the hot phase more than the skipped loops save; profiles/r03/broad_tight_ab.txt) -- the frozen variants always use them.
+#ifndef RR_BROAD_TIGHT
+#define RR_BROAD_TIGHT 0
+#endif
 #if RR_EXACT_TRIG
 // The "exact trig" build (libroborugby_amd_exact.so, BatchedRoboRugbyEnv(exact_trig=True)): sin & cos to ~2^-63 of their true values
 // before the one final rounding, i.e. correctly rounded except on ~1 argument in 10^4.  Why: the reference's math.sin / math.cos
@@ -1685,7 +1691,7 @@ RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, co
                 // (frozen variant only -- it costs the common path nothing: a spurious "close" thaws the island, so the pair also
                 // has to pass the separating-axis test, grown by the 2 x 3 px the two robots can still move; every robot is
                 // still on its frame-begin pose here)
-                if (FZ && PAIRED && cl) cl = !robots_separated(A, r, j, dx, dy, (R)6.05);
+                if ((FZ || RR_BROAD_TIGHT) && PAIRED && cl) cl = !robots_separated(A, r, j, dx, dy, (R)6.05);
                 c_rr = c_rr | cl;
             }
             if (!PAIRED) { // _move_bots
@@ -1716,7 +1722,7 @@ RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, co
                 for (int r2 = 0; r2 < C::NR; r2++) { // ball-robot: 22.36 + 9.9 (+ 3 px of robot motion)
                     R dx = A.p.bcx[l] - A.p.rcx[r2], dy = A.p.bcy[l] - A.p.rcy[r2];
                     bool cl = dx * dx + dy * dy <= (R)(36.0 * 36.0);
-                    if (FZ && PAIRED && cl) { // frozen variant only: the robot-frame bound of ball_near_robot, grown by the same 3 px
+                    if ((FZ || RR_BROAD_TIGHT) && PAIRED && cl) { // the robot-frame bound of ball_near_robot, grown by the same 3 px
                         const R *q = A.rel[r2];
                         const R ux = (q[2] - q[0]) * (R)0.05, uy = (q[3] - q[1]) * (R)0.05, vx = (q[4] - q[0]) * (R)0.025, vy = (q[5] - q[1]) * (R)0.025;
                         cl = (m_abs(dx * ux + dy * uy) <= (R)20.05) & (m_abs(dx * vx + dy * vy) <= (R)30.05);
