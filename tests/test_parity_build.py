@@ -120,3 +120,29 @@ def test_shortcut_equivalence_suites_pass_against_the_parity_build():
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.join(HERE, "test_fixed_point_memo.py"),
                         os.path.join(HERE, "test_budgeted_step.py")], env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("preset", ["T", "G", "D"])
+def test_parity_build_carries_the_scratch_rect_across_resets(preset):
+    """A reset moves the balls, not the scratch rect (RR_EnvBase.py:125-216 never touches RR_TrashyPhysics): three episodes of 40 random
+    steps each with a reset in between, the parity build and the oracle (correctly rounded libm) side by side from the constructor
+    placement on -- bit-identical state after every step, and the rect where the oracle has it."""
+    rng = np.random.RandomState(11)
+    ol.lib().rro_debug_attribution(4)
+    try:
+        for arena in (3, 77):
+            e, o = el.EmuEnv(preset, seed=9, exact=True), ol.OracleEnv(preset)
+            na = e.nr
+            for episode in (0, 1, 2):
+                e.reset(arena, episode)
+                o.reset(9, arena, episode)
+                so, se = o.get_state(), e.get_state()
+                assert _same(so, se), (preset, arena, episode, "placement")
+                for s in range(40):
+                    a = rng.randint(0, 8, na).astype(np.int32)
+                    o.step(a)
+                    e.step(a)
+                    assert _same(o.get_state(), e.get_state()), (preset, arena, episode, s)
+                assert np.array_equal(o.get_state()["inner"][:2], e.get_scratch_rect()), (preset, arena, episode)
+    finally:
+        ol.lib().rro_debug_attribution(0)
