@@ -440,12 +440,15 @@ template <class C> struct ArenaBody {
     R ax[NR], ay[NR], arot[NR]; // pose at frame begin (= ring entry written this frame)
     R psx[NR], psy[NR]; // robot centre at step begin (rectDblPriorStep)
     R bfx[NB], bfy[NB], pfx[NB], pfy[NB];
+#if RR_CARRY
+    uint8_t bmass[NB];         // (1..3; bytes, so that the two reals of P::ic do not cost the G slice its eighth workgroup per CU)
+#else
     int32_t bmass[NB];
+#endif
+    // (parity build: bbm doubles as the per-ball mask of the robots with a corner inside the ball -- the pairs of a ball-robot sweep
+    // that return before touching the scratch rect; the ball-pair sweep's use of it is over by then)
     uint16_t bbm[NB], brc[NB]; // per-ball hit / close bit masks of the contact sweeps (one lane per ball writes its own; 16 bits:
                                // NB <= 11, NR <= 8 -- the G slice has no byte to spare, see wm below)
-#if RR_CARRY
-    uint16_t bcm[NB];         // per-ball mask of the robots with a corner inside the ball (the pairs that return before touching the scratch rect)
-#endif
     R exc[NB];                // how far (L1) the contact responses of this sub-step have carried the ball from its frame-begin centre
     R reach[NB];              // 14.04 + the most the ball can travel in this sub-step's roll: the ball-ball bound of the fused roll phase
     int32_t sides_ok; // sm/sc match the current robot poses (rebuilt lazily by the first phase that needs them)
@@ -853,8 +856,8 @@ template <class C> RR_HD uint32_t detect_robot_pairs(Arena<C> &A) {
 //   * c_in(0) of a sweep and the c_old of a response is A.p.ic, the centre the last user left; it lives in the arena's record
 //     (rr_set_scratch_rect / rr_get_scratch_rect seed and read it), since a reset moves the balls but not the rect.
 template <typename R> RR_HD R carry1(R c_old, R x) { return c_old + (x - c_old); }
-template <class C> RR_HD int corner_free_robots(const Arena<C> &A, int b) { return C::NR - __builtin_popcount((unsigned)A.bcm[b]); }
-// centre of the scratch rect when the sweep reaches ball `upto` (= what ball upto - 1 left behind); bcm[] must be current
+template <class C> RR_HD int corner_free_robots(const Arena<C> &A, int b) { return C::NR - __builtin_popcount((unsigned)A.bbm[b]); }
+// centre of the scratch rect when the sweep reaches ball `upto` (= what ball upto - 1 left behind); the corner masks (A.bbm) must be current
 template <class C> RR_HD V2<typename C::Real> carry_chain(const Arena<C> &A, int upto) {
     using R = typename C::Real;
     V2<R> c = { A.p.ic[0], A.p.ic[1] };
@@ -869,25 +872,46 @@ template <class C> RR_HD V2<typename C::Real> carry_chain(const Arena<C> &A, int
 // the centre pair (b, r) builds its diameters from
 template <class C> RR_HD V2<typename C::Real> carry_centre(const Arena<C> &A, int b, int r) {
     using R = typename C::Real;
-    const unsigned cm = A.bcm[b], low = (1u << r) - 1u;
+    const unsigned cm = A.bbm[b], low = (1u << r) - 1u;
     V2<R> x = { A.p.bcx[b], A.p.bcy[b] };
     if ((cm & low) != low) return x; // a lower robot already moved the rect onto this ball
     const V2<R> c = carry_chain(A, b);
     V2<R> c1 = { carry1<R>(c.x, x.x), carry1<R>(c.y, x.y) };
     return c1;
 }
-// a sweep in which no ball is near any robot (the two the fast path of a sub-step skips, RR_EnvBase.py:335 and :372): every pair
-// reaches the setter
-template <class C> RR_HD void carry_quiet_sweep(Arena<C> &A) {
-    V2<typename C::Real> c = { A.p.bcx[C::NB - 1], A.p.bcy[C::NB - 1] }; // two or more robots: the last ball's later pairs put it there exactly
-    if constexpr (C::NR < 2) {
-        RR_FOR_LANES(l) { if (l < C::NB) A.bcm[l] = 0; }
+// The two sweeps the fast path of a sub-step skips (the push's, RR_EnvBase.py:335, and the resolve loop's one pass, :372) find no ball
+// near any robot: every pair reaches the setter.  With two or more robots the rect therefore ends exactly ON THE LAST BALL whatever it
+// held before; with one robot (one ball) it ends at carry(c, x), which is x again whenever the rect already sat on the ball's previous
+// position and the roll is an exact difference (always, but for a ball flung across half its coordinate in one sub-step).  So on the
+// quiet path nothing is written: `icm` = 1 says "the rect is on the last ball's frame-begin centre (A.pfx/pfy: pre-roll, and the same
+// value as the centre at the end of the previous sub-step) -- or, between sub-steps, on its current centre"; the explicit A.p.ic is
+// brought up to date (carry_materialize) only where somebody reads it: a real sweep, a response, a snapshot, the end of the step.
+template <class C> RR_HD void carry_materialize(Arena<C> &A, int &icm, bool frame_begin) {
+    if (icm) {
         RR_SYNC();
-        c = carry_chain(A, C::NB);
+        if (RR_IS_LANE0) {
+            A.p.ic[0] = frame_begin ? A.pfx[C::NB - 1] : A.p.bcx[C::NB - 1];
+            A.p.ic[1] = frame_begin ? A.pfy[C::NB - 1] : A.p.bcy[C::NB - 1];
+        }
+        RR_SYNC();
+        icm = 0;
     }
-    RR_SYNC();
-    if (RR_IS_LANE0) { A.p.ic[0] = c.x; A.p.ic[1] = c.y; }
-    RR_SYNC();
+}
+// a quiet sweep; `frame_begin`: the balls have not rolled yet (the push's sweep).  One robot: the explicit chain, until it lands on the ball
+template <class C> RR_HD void carry_quiet_sweep(Arena<C> &A, int &icm, bool frame_begin) {
+    if constexpr (C::NR >= 2) {
+        icm = 1;
+    } else {
+        static_assert(C::NR >= 2 || C::NB == 1, "one robot: one ball");
+        if (icm) return; // on the ball already (the roll's exactness is checked in substep_phase2: an inexact one takes the full path)
+        RR_FOR_LANES(l) { if (l < C::NB) A.bbm[l] = 0; }
+        RR_SYNC();
+        const V2<typename C::Real> c = carry_chain(A, C::NB);
+        RR_SYNC();
+        if (RR_IS_LANE0) { A.p.ic[0] = c.x; A.p.ic[1] = c.y; }
+        RR_SYNC();
+        icm = (c.x == A.p.bcx[0] && c.y == A.p.bcy[0]) ? 1 : 0;
+    }
 }
 // the balls outside an island `kb` whose position the island's sweeps and responses depend on through the scratch rect
 template <class C> RR_HD uint32_t carry_deps(uint32_t kb) { return kb ? (((kb >> 1) | (1u << (C::NB - 1))) & ~kb) : 0u; }
@@ -930,7 +954,7 @@ template <class C, bool CACHED> RR_HD uint32_t detect_ball_robot(Arena<C> &A, co
                     cmk |= ch ? (1 << r) : 0;
                 }
             }
-            A.bcm[l] = (uint16_t)cmk;
+            A.bbm[l] = (uint16_t)cmk;
 #else
             for (int r = 0; r < C::NR; r++) msk |= ball_near_robot(A, l, r) ? (1 << r) : 0;
 #endif
@@ -1778,13 +1802,18 @@ RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, co
     }
 }
 template <class C, bool FZ>
-RR_HD void substep_phase2(Arena<C> &A, const SimParams<typename C::Real> &sp, const Hit &fz, uint64_t &m_any) {
+RR_HD void substep_phase2(Arena<C> &A, const SimParams<typename C::Real> &sp, const Hit &fz, uint64_t &m_any, int icm) {
     using R = typename C::Real;
     RR_FOR_LANES(l) {
         bool c = false;
         if (l < C::NB && !(FZ && ((fz.b >> l) & 1u))) {
             ball_move_lane(A, l);
             const R mx = A.p.bcx[l], my = A.p.bcy[l];
+#if RR_CARRY
+            // one robot, the scratch rect riding on the ball (carry_quiet_sweep): a roll that is not an exact difference would leave it
+            // a last bit off the ball -- take the full path, which carries it explicitly
+            if (C::NR < 2 && icm) c = c | (carry1<R>(A.pfx[l], mx) != mx) | (carry1<R>(A.pfy[l], my) != my);
+#endif
             for (int j = 0; j < C::NB; j++) {
                 R dx = A.p.bcx[j] - mx, dy = A.p.bcy[j] - my;
                 R reach = A.reach[j];
@@ -1877,7 +1906,7 @@ template <class C> RR_HD void thaw_island(Arena<C> &A, const SimParams<typename 
 // mid->phase == 1 skips everything before that loop and re-enters it.
 template <class C, bool BUDGET = false>
 RR_HD bool substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t &naughty, int &st, uint32_t &prev_moved,
-                   int &work, Hit &fz, Hit &hit, MidState *mid = nullptr, const ParkCtx *pk = nullptr) {
+                   int &work, Hit &fz, Hit &hit, int &icm, MidState *mid = nullptr, const ParkCtx *pk = nullptr) {
     using R = typename C::Real;
     uint32_t bots_moved = ((1u << C::NR) - 1) & ~fz.r, balls_moved = (1u << C::NB) - 1;
     RR_TRACE("E substep\n");
@@ -1914,6 +1943,9 @@ RR_HD bool substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     }
     RR_STAMP(2);
     if (RR_UNLIKELY(m_br)) { // _push_balls (RR_EnvBase.py:335-339): frozen hit list, ball-major order
+#if RR_CARRY
+        carry_materialize(A, icm, true);
+#endif
         // (with fewer than eight lanes per arena a lane of the uncached variant sweeps all four sides and builds every robot-only
         // operand itself -- nine dependent divisions; going through the caches is shorter there: T 650 -> 690 M env-steps/s)
         uint32_t br = (C::VW < 8) ? detect_ball_robot<C, true>(A, sp) : detect_ball_robot<C, false>(A, sp);
@@ -1922,15 +1954,15 @@ RR_HD bool substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
         push_balls(A, sp, br, bots_moved, st, hit);
     }
 #if RR_CARRY
-    else carry_quiet_sweep(A); // the push sweep the fast path skips still walks the scratch rect over every ball
+    else carry_quiet_sweep(A, icm, true); // the push sweep the fast path skips still walks the scratch rect over every ball
 #endif
     RR_STAMP(3);
     // phase 2: _roll_balls AND the fused first pass of _resolve_ball_collisions: anything possibly touching?  Ball-ball
     // runs in the same phase as the roll, so the other ball may be seen before or after its own roll: the bound (A.reach,
     // written at the frame hooks and refreshed by the push) adds the most it can travel in its roll.  Ball-robot uses the settled robot centres; the wall test is the exact int-rect test.
     RR_TRACE("E phase1 rr %d br %d\n", (int)(m_rr != 0), (int)(m_br != 0));
-    if (RR_UNLIKELY(frozen && (fz.r | fz.b))) substep_phase2<C, true>(A, sp, fz, m_any);
-    else substep_phase2<C, false>(A, sp, fz, m_any);
+    if (RR_UNLIKELY(frozen && (fz.r | fz.b))) substep_phase2<C, true>(A, sp, fz, m_any, icm);
+    else substep_phase2<C, false>(A, sp, fz, m_any, icm);
     RR_SYNC();
     RR_STAMP(4);
     if (RR_UNLIKELY((fz.r | fz.b) && m_any)) { // thaw after the roll phase: the island catches up (move, push, roll), then the full path
@@ -1941,14 +1973,21 @@ RR_HD bool substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
         // the push saw the other balls before their roll and found none of them near a robot (phase 1): only K's pairs count
         uint32_t kmask = 0;
         for (int b = 0; b < C::NB; b++) if ((k.b >> b) & 1u) kmask |= ((1u << C::NR) - 1u) << (b * C::NR);
-        uint32_t br = detect_ball_robot<C, false>(A, sp) & kmask;
-        push_balls(A, sp, br, bots_moved, st, hit);
-        RR_FOR_LANES(l) { if (l < C::NB && ((k.b >> l) & 1u)) ball_move_lane(A, l); }
-        RR_SYNC();
+        if (k.b) { // (an island of robots only has no pair to push)
+#if RR_CARRY
+            // the push's sweep, late: the balls it depends on through the scratch rect stand still or are the island's, not yet rolled
+            carry_materialize(A, icm, true);
+#endif
+            uint32_t br = detect_ball_robot<C, false>(A, sp) & kmask;
+            push_balls(A, sp, br, bots_moved, st, hit);
+            RR_FOR_LANES(l) { if (l < C::NB && ((k.b >> l) & 1u)) ball_move_lane(A, l); }
+            RR_SYNC();
+        }
     }
     RR_TRACE("E phase2 any %d\n", (int)(m_any != 0));
 #if RR_CARRY
-    if (!m_any) carry_quiet_sweep(A); // ... and so does the one pass of the resolve loop
+    if (!m_any) carry_quiet_sweep(A, icm, false); // ... and so does the one pass of the resolve loop
+    else carry_materialize(A, icm, true);         // (the push's sweep was quiet: the rect is where the last ball was before the roll)
 #endif
     } // !reentry
     if (RR_UNLIKELY(m_any)) { // the reference's loop, from its first pass (nothing has changed since the broad phase above)
@@ -2554,6 +2593,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     uint32_t fz_bits = 0; // NaughtyBots members + status bits of one computed sub-step of the frozen island (fz_pack_bits)
     int f0 = 0; // first sub-step to run: 0, or where a parked step goes on
     MidState mid; // (budgeted step: a sub-step parked between two passes of its resolve loop re-enters there)
+    int icm = 0;  // parity build: 1 while the scratch rect is implicitly on the last ball (carry_quiet_sweep); 0: A.p.ic holds it
     constexpr bool FZP = C::NR <= 4 && C::NB <= 8; // what the packed word holds
     bool resumed = false;
     RR_T0();
@@ -2662,7 +2702,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
         uint32_t n_sub = 0; // what THIS sub-step adds: a freeze keeps it for the frozen sub-steps of later steps
         int st_sub = 0;
         if constexpr (BUDGET) {
-            const bool parked_mid = substep<C, true>(A, sp, n_sub, st_sub, prev_moved, work, fz, hit, &mid, &pk);
+            const bool parked_mid = substep<C, true>(A, sp, n_sub, st_sub, prev_moved, work, fz, hit, icm, &mid, &pk);
             if (RR_UNLIKELY(parked_mid)) {
                 RR_TRACE("E parked inside sub-step %d before resolve pass %d\n", f, mid.count + 1);
                 park_save(A, pk.buf, f, prev_moved, naughty, st, fz, fz_bits, snap_at == f - 1, snap_moved, dist_sum0, mid);
@@ -2674,7 +2714,7 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
                 return;
             }
         } else {
-            substep(A, sp, n_sub, st_sub, prev_moved, work, fz, hit);
+            substep(A, sp, n_sub, st_sub, prev_moved, work, fz, hit, icm);
         }
         naughty |= n_sub; st |= st_sub;
 #if defined(RR_PROFILE_PHASES) // diagnostic builds only: the step's contact work in status bits 20-29, "began frozen" in bit 30
@@ -2688,6 +2728,9 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
             uint32_t chg_r, chg_re, chg_b;
             bool ax_diff;
             const bool have = snap_at == f - 1;
+#if RR_CARRY
+            carry_materialize(A, icm, false); // (the snapshot holds the explicit centre)
+#endif
             snapshot_compare_update(A, o.snap(), o.isnap(), have, chg_r, chg_re, chg_b, ax_diff);
             RR_TRACE("E snapshot at %d: have %d chg_r %x edges %x chg_b %x hit r %x b %x moved %x/%x work %d\n", f, (int)have, chg_r, chg_re, chg_b, hit.r, hit.b, prev_moved, snap_moved, work);
             if (have) {
@@ -2722,6 +2765,9 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
         if constexpr (BUDGET) { // over the budget after an expensive sub-step, and more to come: park at this boundary
             if (f + 1 < RR_NUM_SUBSTEPS && RR_UNLIKELY(pk.over(work))) {
                 RR_TRACE("E parked after sub-step %d\n", f);
+#if RR_CARRY
+                carry_materialize(A, icm, false);
+#endif
                 park_save(A, pk.buf, f + 1, prev_moved, naughty, st, fz, fz_bits, snap_at == f, snap_moved, dist_sum0, mid);
                 if (RR_IS_LANE0) {
                     *o.reward() = (O)0; *o.done() = 0;
@@ -2746,6 +2792,9 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     } else if (BUDGET) {
         if (RR_IS_LANE0) A.i.fzp = 0; // (configurations without a carried island: the word only ever holds the parked mark)
     }
+#if RR_CARRY
+    carry_materialize(A, icm, false); // the record carries the explicit centre from step to step (a reset moves the balls, not the rect)
+#endif
     substeps_end(A, prev_moved);
     RR_STAMP(9);
     // ---- on_step_end: NaughtyBots, ChasePosBall, PushPosBallsToGoal (SURVEY 3.1 accumulation order)
