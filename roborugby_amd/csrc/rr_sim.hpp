@@ -166,7 +166,8 @@ RR_HD float m_rint(float x) { return ::rintf(x); }
 #define RR_EXACT_TRIG 0
 #endif
 // The parity build also carries the centre of the reference's module-global scratch rect (_rectBallInner, RR_TrashyPhysics.py:26-36)
-// from one use to the next: see "scratch-rect carry" below.  fp64 configurations only (the fp32 mode is not a parity mode).
+// from one use to the next: see "scratch-rect carry" below.  (Every instantiation of that build carries it; only its fp64
+// configurations are parity modes -- BatchedRoboRugbyEnv refuses exact_trig with dtype f32.)
 #ifndef RR_CARRY
 #define RR_CARRY RR_EXACT_TRIG
 #endif
