@@ -15,13 +15,14 @@ def _close(a, b, tol=TOL):
     return np.array_equal(np.isnan(a), np.isnan(b)) and (np.nan_to_num(np.abs(a - b)).max() if a.size else 0.0) < tol
 
 
-@pytest.mark.parametrize("preset", ["T", "G"])
+@pytest.mark.parametrize("preset", ["T", "G", "D"])
 def test_emulated_side_kernels_vs_reference_golden(golden_dir, preset):
     t = np.load(f"{golden_dir}/mix_{preset}.npz")
     meta = json.loads(str(t["meta"]))
     progs = {0: meta["programs_exec"]["A"], 1: meta["programs_exec"]["B"]}
-    has_g = preset == "G"
-    nr, nb = (4, 8) if has_g else (1, 1)
+    cfg = el.ol.PRESETS[preset]
+    has_g = cfg["nr_g"] > 0
+    nr, nb = cfg["nr_h"] + cfg["nr_g"], cfg["nb_p"] + cfg["nb_n"]
     n = 0
     for ep in range(t["length"].shape[0]):
         env = el.EmuEnv(preset)
@@ -55,7 +56,7 @@ def test_keeper_exec_order_rule():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("preset", ["T", "G"])
+@pytest.mark.parametrize("preset", ["T", "G", "D"])
 def test_gpu_mixin_stacks_vs_reference_golden(golden_dir, preset):
     import torch
     import roborugby_amd as rr
@@ -88,7 +89,7 @@ def test_gpu_mixin_stacks_vs_reference_golden(golden_dir, preset):
             assert _close(got, t[f"allp_{'h' if team == 1 else 'g'}"][ep, st]), (preset, which, "AllCoords_WithPrior", team)
         with pytest.raises(RuntimeError):
             env.get_game_state(1, observer="AllCoords_WithPrior")  # this env never asked for the snapshot
-        if preset == "G":
+        if rr.PRESETS[preset].nr_grumpy > 0:
             got = env.get_game_state(-1, f64=True, observer="SingleBall_6wayLidar").cpu().numpy()
             assert _close(got, t["v1_g"][ep, st])
         else:
