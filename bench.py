@@ -377,7 +377,7 @@ def main():
                        "sharding": f"dp{world} (independent arena shards, returns all-gathered every "
                                    f"{gather_every} steps and once after the loop)" if world > 1 else "single GPU",
                        "steps_per_launch": F, "fault_status_bits_seen": status_bits, "staggered_phases": bool(stagger),
-                       "parity_mode": args.dtype == "f64", "exact_trig": bool(args.exact_trig),
+                       "fp64_arithmetic": args.dtype == "f64", "exact_trig": bool(args.exact_trig),
                        "step_budget_clocks": args.budget, "not_ready_fraction": n_not_ready / float(n * K),
                        "collectives": {"all_gather_calls": len(pending), "ranks": world, "backend": rrd.backend_name(),
                                        "bytes_per_rank": 4 * n, "gathered_rows": gathered_rows[-1] if gathered_rows else 0,

@@ -133,8 +133,15 @@ class RRError(RuntimeError):
     pass
 
 
-def check(rc, what, lib=None):
+def check(rc, what, lib=None, err_fn="rr_last_error"):
+    """Raises RRError with the message of the library that returned `rc` (`lib`; the env passes its own -- the default and the
+    parity library keep separate thread-local strings).  `err_fn`: the entry point that holds the message -- the rr_dqn_* calls
+    write theirs to rr_dqn_last_error."""
     if rc != 0:
         libs = [lib] if lib is not None else [x for x in (_lib, _lib_exact) if x is not None] or [load()]
-        msg = b"; ".join(m for m in (x.rr_last_error() for x in libs) if m)
+        msg = b"; ".join(m for m in (getattr(x, err_fn)() for x in libs) if m)
         raise RRError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def check_dqn(rc, what, lib):
+    check(rc, what, lib, "rr_dqn_last_error")

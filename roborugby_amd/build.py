@@ -19,7 +19,6 @@ LIB = os.path.join(HERE, "libroborugby_amd.so")
 # the exact-trig parity build: the same sources with -DRR_EXACT_TRIG=1 (sin / cos of the robot kinematics in double-double, ~correctly
 # rounded: agrees with the reference's glibc in 99.8 % of the evaluations instead of 97 %; csrc/rr_sim.hpp) -- opt-in, slower
 LIB_EXACT = os.path.join(HERE, "libroborugby_amd_exact.so")
-STAMP = LIB + ".srchash"
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 
@@ -91,6 +90,8 @@ def build_hip_library(force=False, verbose=False, jobs=None, exact=False):
     return lib_path
 
 
-if __name__ == "__main__":
-    print(build_hip_library(force=True, verbose=True))
-    print(build_hip_library(force=True, verbose=True, exact=True))
+if __name__ == "__main__":  # python -m roborugby_amd.build [--force]: rebuilds what is stale (everything with --force)
+    import sys
+    _force = "--force" in sys.argv[1:]
+    print(build_hip_library(force=_force, verbose=True))
+    print(build_hip_library(force=_force, verbose=True, exact=True))

@@ -128,9 +128,22 @@ class BatchedDQNAgent:
             from . import _lib
             self._rrlib = _lib.load()
             h = C.c_void_p()
-            _lib.check(self._rrlib.rr_dqn_create(self.device.index or 0, C.byref(h)), "rr_dqn_create")
+            _lib.check_dqn(self._rrlib.rr_dqn_create(self.device.index or 0, C.byref(h)), "rr_dqn_create", self._rrlib)
             self._fused_h = h
             self._fused_loss = torch.zeros(1, device=self.device)
+        self._act_calls = 0  # choose_action calls so far: keys the fused kernel's epsilon draws (checkpointed)
+
+    def close(self):
+        """rr_dqn_destroy: the handle holds the per-workgroup partial gradients and the Adam moments (~73 MB of device memory)."""
+        h, self._fused_h = getattr(self, "_fused_h", None), None
+        if h:
+            self._rrlib.rr_dqn_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @torch.no_grad()
     def choose_action(self, observation, epsilon_override=None):
@@ -178,10 +191,10 @@ class BatchedDQNAgent:
         if not hasattr(self, "_store_count"):
             self._store_count = torch.zeros(1, dtype=torch.int32, device=self.device)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
-        _lib.check(self._rrlib.rr_dqn_store(self._fused_h, p(s), p(a), p(r), p(s2), p(d), p(v), n, self.mem_cntr, self.mem_size,
+        _lib.check_dqn(self._rrlib.rr_dqn_store(self._fused_h, p(s), p(a), p(r), p(s2), p(d), p(v), n, self.mem_cntr, self.mem_size,
                                             p(self.state_memory), p(self.new_state_memory), p(self.action_memory), p(self.reward_memory),
                                             p(self.terminal_memory), p(self._store_count),
-                                            C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "rr_dqn_store")
+                                            C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "rr_dqn_store", self._rrlib)
         self.mem_cntr += n if v is None else int(self._store_count.item())  # (the one host read of the call, as in the PyTorch path)
 
     def _sample(self, max_mem):
@@ -196,10 +209,10 @@ class BatchedDQNAgent:
         n = obs.shape[0]
         out = torch.empty(n, dtype=torch.int32, device=self.device)
         ptrs = (C.c_void_p * 6)(*[p.data_ptr() for p in self.Q_eval.parameters()])
-        self._act_calls = getattr(self, "_act_calls", 0) + 1
-        _lib.check(self._rrlib.rr_dqn_act(self._fused_h, C.byref(ptrs), C.c_void_p(obs.data_ptr()), n, float(min(max(eps, 0.0), 1.0)),
+        self._act_calls += 1
+        _lib.check_dqn(self._rrlib.rr_dqn_act(self._fused_h, C.byref(ptrs), C.c_void_p(obs.data_ptr()), n, float(min(max(eps, 0.0), 1.0)),
                                           int(self._seed), self._act_calls & 0xFFFFFFFF, C.c_void_p(out.data_ptr()), None,
-                                          C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "rr_dqn_act")
+                                          C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "rr_dqn_act", self._rrlib)
         self._keep_obs = obs  # read asynchronously
         return out
 
@@ -223,8 +236,8 @@ class BatchedDQNAgent:
         from . import _lib
         batch = self._sample(max_mem).contiguous()
         args = self._fused_args(batch)
-        _lib.check(self._rrlib.rr_dqn_update(self._fused_h, C.byref(args), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
-                   "rr_dqn_update")
+        _lib.check_dqn(self._rrlib.rr_dqn_update(self._fused_h, C.byref(args), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                   "rr_dqn_update", self._rrlib)
         self._keep = batch  # the launch reads it asynchronously
         return self._fused_loss[0]
 
@@ -234,8 +247,8 @@ class BatchedDQNAgent:
         n = self._rrlib.rr_dqn_param_count()
         flat = torch.empty(n, device=self.device)
         args = self._fused_args(batch.contiguous())
-        _lib.check(self._rrlib.rr_dqn_grads(self._fused_h, C.byref(args), C.c_void_p(flat.data_ptr()),
-                                            C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "rr_dqn_grads")
+        _lib.check_dqn(self._rrlib.rr_dqn_grads(self._fused_h, C.byref(args), C.c_void_p(flat.data_ptr()),
+                                            C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "rr_dqn_grads", self._rrlib)
         torch.cuda.current_stream(self.device).synchronize()
         names = ["fc2.weight", "fc1.weight", "fc3.weight", "fc1.bias", "fc2.bias", "fc3.bias"]  # the handle's flat order
         shapes = dict(self.Q_eval.named_parameters())
@@ -348,25 +361,68 @@ class BatchedDQNAgent:
             m1, m2 = state["exp_avg"].to(self.device).contiguous(), state["exp_avg_sq"].to(self.device).contiguous()
             step = C.c_int64(int(state["step"]))
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        _lib.check(self._rrlib.rr_dqn_adam_state(self._fused_h, C.c_void_p(m1.data_ptr()), C.c_void_p(m2.data_ptr()), C.byref(step),
-                                                 0 if state is None else 1, st), "rr_dqn_adam_state")
+        _lib.check_dqn(self._rrlib.rr_dqn_adam_state(self._fused_h, C.c_void_p(m1.data_ptr()), C.c_void_p(m2.data_ptr()), C.byref(step),
+                                                 0 if state is None else 1, st), "rr_dqn_adam_state", self._rrlib)
         torch.cuda.current_stream(self.device).synchronize()
         return dict(exp_avg=m1, exp_avg_sq=m2, step=step.value)
 
+    # flat layout of the fused step's Adam moments (csrc/rr_dqn.hip: OFF_W2, OFF_W1, OFF_W3, OFF_B1, OFF_B2, OFF_B3) as indices
+    # into Q_eval.parameters() = fc1.weight, fc1.bias, fc2.weight, fc2.bias, fc3.weight, fc3.bias
+    _FUSED_ORDER = (2, 0, 4, 1, 3, 5)
+
+    def _flat_from_torch_adam(self, opt_sd):
+        """torch.optim.Adam state_dict -> the fused layout; None if the optimizer was never stepped"""
+        st = opt_sd.get("state", {})
+        if len(st) < 6:
+            return None
+        params = list(self.Q_eval.parameters())
+        cat = lambda key: torch.cat([st[k][key].detach().to(self.device, torch.float32).reshape(-1) for k in self._FUSED_ORDER])
+        step = int(torch.as_tensor(st[0]["step"]).item())
+        assert sum(params[k].numel() for k in self._FUSED_ORDER) == cat("exp_avg").numel()
+        return dict(exp_avg=cat("exp_avg"), exp_avg_sq=cat("exp_avg_sq"), step=step)
+
+    def _torch_adam_from_flat(self, flat):
+        """the fused layout -> the `state` part of a torch.optim.Adam state_dict for Q_eval's parameters"""
+        params = list(self.Q_eval.parameters())
+        state, off = {}, 0
+        for k in self._FUSED_ORDER:
+            n = params[k].numel()
+            state[k] = dict(step=torch.tensor(float(flat["step"]), device=self.device),
+                            exp_avg=flat["exp_avg"][off:off + n].reshape(params[k].shape).clone(),
+                            exp_avg_sq=flat["exp_avg_sq"][off:off + n].reshape(params[k].shape).clone())
+            off += n
+        return state
+
     def state_dict(self):
-        sd = dict(q_eval=self.Q_eval.state_dict(), q_target=self.Q_target.state_dict(),
-                  optimizer=self.Q_eval.optimizer.state_dict(), epsilon=self.epsilon, mem_cntr=self.mem_cntr,
-                  next_target_sync=self._next_target_sync, updates=self.updates, target_syncs=self.target_syncs)
+        """Both optimizer representations travel, so a checkpoint written by the fused agent resumes under --no-fused and the
+        other way round: `optimizer` (torch.optim.Adam's) and `fused_adam` (flat moments + step) describe the same Adam state."""
+        opt = self.Q_eval.optimizer.state_dict()
+        sd = dict(q_eval=self.Q_eval.state_dict(), q_target=self.Q_target.state_dict(), epsilon=self.epsilon, mem_cntr=self.mem_cntr,
+                  next_target_sync=self._next_target_sync, updates=self.updates, target_syncs=self.target_syncs,
+                  act_calls=self._act_calls, fused=self.fused)
         if self.fused:
             sd["fused_adam"] = self._fused_adam()
+            if sd["fused_adam"]["step"] > 0:  # the torch optimizer is never stepped in fused mode: write the moments in its format too
+                opt = dict(opt, state=self._torch_adam_from_flat(sd["fused_adam"]))
+        else:
+            flat = self._flat_from_torch_adam(opt)
+            if flat is not None:
+                sd["fused_adam"] = flat
+        sd["optimizer"] = opt
         return sd
 
     def load_state_dict(self, sd, lr_override=0.0, epsilon_override=0.0, eps_dec_override=0.0):
         self.Q_eval.load_state_dict(sd["q_eval"])
         self.Q_target.load_state_dict(sd["q_target"])
         self.Q_eval.optimizer.load_state_dict(sd["optimizer"])
-        if self.fused and "fused_adam" in sd:
-            self._fused_adam(sd["fused_adam"])
+        if self.fused:
+            flat = sd.get("fused_adam") or self._flat_from_torch_adam(sd["optimizer"])
+            if flat is not None:
+                self._fused_adam(flat)
+            elif sd.get("updates", 0) > 0:
+                import warnings
+                warnings.warn("checkpoint carries no Adam moments for the fused learn step: Adam restarts from zero moments")
+        self._act_calls = int(sd.get("act_calls", 0))
         self.epsilon = sd["epsilon"]
         self.updates, self.target_syncs = sd.get("updates", 0), sd.get("target_syncs", 0)
         # The replay memory is not checkpointed (the reference pickles it with the agent), so the transition counter
@@ -427,10 +483,7 @@ def train(num_envs=65536, steps=300, preset="T", device="cuda:0", seed=0, checkp
     if resume:
         ck = torch.load(resume, map_location=device)
         agent.load_state_dict(ck["agent"])
-        st = ck["env_state"]
-        env.set_state(st["robots"], st["robots_i"], st["balls"], st["step"])
-        if "episode" in ck:  # episode index (reset RNG key), running returns, counters: the run continues, it does not restart
-            env.set_episode_state(ck["episode"]["ints"], ck["episode"]["acc"])
+        env.load_checkpoint_state(ck)  # state, episode bookkeeping (the episode index keys the reset RNG), parity build: the scratch rect
         observation = env.get_game_state()
     else:
         observation = env.reset()
@@ -471,6 +524,10 @@ def train(num_envs=65536, steps=300, preset="T", device="cuda:0", seed=0, checkp
                     agent.learn()
                 learned = torch.cuda.Event()
                 learned.record(side)
+        if step_budget_clocks and checkpoint and i == steps - 1:
+            # a checkpoint must not catch an arena parked mid-step (rr_set_state on resume would drop the rest of that step and
+            # the action it accepted): the last call before it runs synchronously -- parked arenas finish, nobody parks
+            env.set_step_budget(0)
         observation_, reward, done, info = env.step(acts)
         real = (info.status & (1024 | 16384)) == 0  # a call that only re-placed the arena, or left its step unfinished, is not a transition
         if step_budget_clocks:
@@ -511,7 +568,7 @@ def train(num_envs=65536, steps=300, preset="T", device="cuda:0", seed=0, checkp
     dt = time.perf_counter() - t0 - t_eval
     if checkpoint:
         os.makedirs(os.path.dirname(os.path.abspath(checkpoint)), exist_ok=True)
-        torch.save(dict(agent=agent.state_dict(), env_state=env.get_state(), episode=env.get_episode_state()), checkpoint)
+        torch.save(dict(agent=agent.state_dict(), **env.checkpoint_state()), checkpoint)
     lr_, _, ll, cnt = env.episode_stats()
     n_real = int(real_rows.item())
     # env steps = the rows that stepped an arena (auto-reset calls count, as in bench.py's random line they are subtracted only there;

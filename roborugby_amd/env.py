@@ -135,7 +135,7 @@ class BatchedRoboRugbyEnv:
         self.step_budget_clocks = int(step_budget_clocks)
         self._bout = None  # persistent step outputs of the budgeted mode (NOT_READY rows keep their previous observation)
         h = C.c_void_p()
-        _lib.check(self._lib.rr_create(C.byref(cfg), C.byref(h)), "rr_create")
+        _lib.check(self._lib.rr_create(C.byref(cfg), C.byref(h)), "rr_create", self._lib)
         self._h = h
         # other mixin stacks of the reference: `rewards` in class order like the reference's env classes
         # (RR_Environments.py), `observer` one of OBSERVERS.  SimpleDuel3's own stack is the default and stays fused in
@@ -145,18 +145,18 @@ class BatchedRoboRugbyEnv:
         self.observer, self.obs_kind = observer, OBSERVERS[observer]
         self.obs_dim = observer_dim(self.obs_kind, p.nr, p.nb)
         if self.obs_kind == 4:  # the prior-step copies have to be snapshotted at every on_step_begin from now on
-            _lib.check(self._lib.rr_track_prior_step(self._h, 1, self._stream()), "rr_track_prior_step")
+            _lib.check(self._lib.rr_track_prior_step(self._h, 1, self._stream()), "rr_track_prior_step", self._lib)
         self.rewards = tuple(rewards)
         prog = np.asarray(keeper_exec_order(self.rewards), np.int32)
         _lib.check(self._lib.rr_set_reward_program(self._h, prog.ctypes.data_as(C.c_void_p), len(prog)),
-                   "rr_set_reward_program")
+                   "rr_set_reward_program", self._lib)
         # Opt-in goal scoring -- an EXTENSION: the reference's goals never score on its live path
         # (RR_Goal.py:58-91 is only reached from the never-called __old_step and is broken), so this has no reference behaviour
         # to match.  A ball inside a goal triangle for 150 consecutive steps is consumed (out of play), +-500 points, three
         # negative balls destroy a goal, a destroyed goal / an empty field ends the episode (include/roborugby_amd.h).
         self.goal_scoring = bool(goal_scoring)
         if self.goal_scoring:
-            _lib.check(self._lib.rr_set_goal_scoring(self._h, 1, self._stream()), "rr_set_goal_scoring")
+            _lib.check(self._lib.rr_set_goal_scoring(self._h, 1, self._stream()), "rr_set_goal_scoring", self._lib)
         m = max(p.arena_w, p.arena_h, 360)  # RR_Observers.py:30-37
         self.observation_space = Box(-m, m, (self.obs_dim,), np.float32)
         # GameEnv_Simple: Discrete(8) (RR_EnvBase.py:610); bare GameEnv: Box(-1, 1, (2*happy robots,)) (RR_EnvBase.py:118-123),
@@ -188,6 +188,8 @@ class BatchedRoboRugbyEnv:
             b = b.expand(self.num_envs, p.nb, 2)
             self._start_balls = torch.cat([b, torch.zeros_like(b)], dim=2).contiguous()
             self._reset_to_start(None, None)
+        if self.step_budget_clocks:
+            self._seed_bout()
 
     # ---------------------------------------------------------------- helpers
     @property
@@ -200,10 +202,24 @@ class BatchedRoboRugbyEnv:
     def _new(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)
 
+    def _seed_bout(self):
+        """Budgeted mode: the persistent step outputs, with both teams' observation rows holding the CURRENT observation -- a row
+        that is NOT_READY in the next step() is not written by the kernel and must read as the arena's previous observation
+        (called wherever a budget is switched on or the arenas are rewritten from outside: reset, set_state, set_poses)."""
+        N = self.num_envs
+        if self._bout is None:
+            self._bout = (self._new((N, 11), torch.float32), torch.zeros(N, dtype=torch.float32, device=self.device),
+                          torch.zeros(N, dtype=torch.uint8, device=self.device),
+                          self._new((N, 11), torch.float32) if self.has_grumpy else None,
+                          torch.zeros(N, dtype=torch.float32, device=self.device), torch.zeros(N, dtype=torch.int32, device=self.device))
+        _lib.check(self._lib.rr_observe(self._h, 1, -1, -1, _ptr(self._bout[0]), self._stream()), "rr_observe", self._lib)
+        if self.has_grumpy:
+            _lib.check(self._lib.rr_observe(self._h, -1, -1, -1, _ptr(self._bout[3]), self._stream()), "rr_observe", self._lib)
+
     # ---------------------------------------------------------------- gym surface
     def _reset_to_start(self, mask, obs):
         _lib.check(self._lib.rr_reset_to_poses(self._h, _ptr(mask), _ptr(self._start_robots), _ptr(self._start_balls), _ptr(obs),
-                                               None, self._stream()), "rr_reset_to_poses")
+                                               None, self._stream()), "rr_reset_to_poses", self._lib)
 
     def _mask(self, mask):
         """uint8 [N] device mask; scalars / wrong sizes are rejected (the kernels index mask[arena] for every arena)."""
@@ -226,13 +242,13 @@ class BatchedRoboRugbyEnv:
         mask = self._mask(mask)
         if mask is not None:
             # rows that are not reset keep their current observation
-            _lib.check(self._lib.rr_observe(self._h, 1, -1, -1, _ptr(obs), self._stream()), "rr_observe")
+            _lib.check(self._lib.rr_observe(self._h, 1, -1, -1, _ptr(obs), self._stream()), "rr_observe", self._lib)
         if bln_randomize_pos:
-            _lib.check(self._lib.rr_reset(self._h, _ptr(mask), _ptr(obs), None, self._stream()), "rr_reset")
+            _lib.check(self._lib.rr_reset(self._h, _ptr(mask), _ptr(obs), None, self._stream()), "rr_reset", self._lib)
         else:
             self._reset_to_start(mask, obs)
-        if self._bout is not None:  # budgeted mode: a row that is NOT_READY in the next step must find this observation
-            self._bout[0].copy_(obs)
+        if self._bout is not None or self.step_budget_clocks:  # budgeted mode: a NOT_READY row of the next step keeps these observations
+            self._seed_bout()
         return obs if self.obs_kind == 0 else self.get_game_state(1)
 
     def starting_positions(self):
@@ -258,9 +274,7 @@ class BatchedRoboRugbyEnv:
         own = out is None and bool(self.step_budget_clocks)
         if own:
             if self._bout is None:  # rows of parked arenas are not written: they must find their previous observation here
-                self._bout = (torch.zeros(N, 11, device=self.device), self._new((N,), torch.float32), self._new((N,), torch.uint8),
-                              torch.zeros(N, 11, device=self.device) if self.has_grumpy else None, self._new((N,), torch.float32),
-                              self._new((N,), torch.int32))
+                self._seed_bout()
             out = self._bout
         if out is None:
             obs, rew = self._new((N, 11), torch.float32), self._new((N,), torch.float32)
@@ -271,7 +285,7 @@ class BatchedRoboRugbyEnv:
         else:
             obs, rew, done, obs_g, rew_g, status = out
         _lib.check(self._lib.rr_step(self._h, _ptr(a), a.shape[1], _ptr(obs), _ptr(rew), _ptr(done), _ptr(obs_g),
-                                     _ptr(rew_g), _ptr(status), self._stream()), "rr_step")
+                                     _ptr(rew_g), _ptr(status), self._stream()), "rr_step", self._lib)
         if own:  # hand out copies: the persistent buffers are overwritten by the next call
             obs, rew, done, rew_g, status = obs.clone(), rew.clone(), done.clone(), rew_g.clone(), status.clone()
             obs_g = obs_g.clone() if obs_g is not None else None
@@ -281,8 +295,10 @@ class BatchedRoboRugbyEnv:
 
     def set_step_budget(self, clocks):
         """rr_set_step_budget: switch the budgeted step on (clocks > 0) or off (0: parked arenas finish in the next calls)."""
-        _lib.check(self._lib.rr_set_step_budget(self._h, int(clocks)), "rr_set_step_budget")
+        _lib.check(self._lib.rr_set_step_budget(self._h, int(clocks)), "rr_set_step_budget", self._lib)
         self.step_budget_clocks = int(clocks)
+        if self.step_budget_clocks:
+            self._seed_bout()
 
     def rollout(self, actions, repeat=None, out=None):
         """Open-loop rollout in ONE launch: `actions` int [S, N] / [S, N, NA] steps the batch S times (or, with
@@ -309,7 +325,7 @@ class BatchedRoboRugbyEnv:
                    self._new((S, N), torch.int32))
         obs, rew, done, obs_g, rew_g, status = out
         _lib.check(self._lib.rr_rollout(self._h, _ptr(a), na, S, rep, _ptr(obs), _ptr(rew), _ptr(done), _ptr(obs_g), _ptr(rew_g),
-                                        _ptr(status), self._stream()), "rr_rollout")
+                                        _ptr(status), self._stream()), "rr_rollout", self._lib)
         return obs, rew, done.view(torch.bool), DebugInfo(obs_g, rew_g, status)
 
     def step_thrust(self, thrust, f64=False):
@@ -326,7 +342,7 @@ class BatchedRoboRugbyEnv:
         rew_g, status = self._new((N,), od), self._new((N,), torch.int32)
         fn = self._lib.rr_step_thrust_f64 if f64 else self._lib.rr_step_thrust
         _lib.check(fn(self._h, _ptr(t), t.shape[1] // 2, _ptr(obs), _ptr(rew), _ptr(done),
-                      _ptr(obs_g), _ptr(rew_g), _ptr(status), self._stream()), "rr_step_thrust")
+                      _ptr(obs_g), _ptr(rew_g), _ptr(status), self._stream()), "rr_step_thrust", self._lib)
         if self.obs_kind != 0:
             obs, obs_g = self.get_game_state(1), (self.get_game_state(-1) if self.has_grumpy else None)
         return obs, rew, done.view(torch.bool), DebugInfo(obs_g, rew_g, status)
@@ -341,7 +357,7 @@ class BatchedRoboRugbyEnv:
         obs_g = self._new((N, 11), torch.float64) if self.has_grumpy else None
         rew_g, status = self._new((N,), torch.float64), self._new((N,), torch.int32)
         _lib.check(self._lib.rr_step_f64(self._h, _ptr(a), a.shape[1], _ptr(obs), _ptr(rew), _ptr(done), _ptr(obs_g),
-                                         _ptr(rew_g), _ptr(status), self._stream()), "rr_step_f64")
+                                         _ptr(rew_g), _ptr(status), self._stream()), "rr_step_f64", self._lib)
         return obs, rew, done.view(torch.bool), DebugInfo(obs_g, rew_g, status)
 
     def get_game_state(self, int_team=None, robot_idx=-1, ball_idx=-1, f64=False, observer=None):
@@ -354,7 +370,7 @@ class BatchedRoboRugbyEnv:
         dim = observer_dim(kind, self.preset.nr, self.preset.nb)
         obs = self._new((self.num_envs, dim), torch.float64 if f64 else torch.float32)
         fn = self._lib.rr_observe_kind_f64 if f64 else self._lib.rr_observe_kind
-        _lib.check(fn(self._h, kind, team, int(robot_idx), int(ball_idx), _ptr(obs), dim, self._stream()), "rr_observe_kind")
+        _lib.check(fn(self._h, kind, team, int(robot_idx), int(ball_idx), _ptr(obs), dim, self._stream()), "rr_observe_kind", self._lib)
         return obs
 
     def render(self, mode="human", arena=0):
@@ -394,19 +410,19 @@ class BatchedRoboRugbyEnv:
         balls = self._new((N, p.nb, 8), torch.float64)
         step = self._new((N,), torch.int32)
         _lib.check(self._lib.rr_get_state(self._h, _ptr(robots), _ptr(robots_i), _ptr(balls), _ptr(step), self._stream()),
-                   "rr_get_state")
+                   "rr_get_state", self._lib)
         return dict(robots=robots, robots_i=robots_i, balls=balls, step=step)
 
     def set_scratch_rect(self, xy):
         """Parity build only (exact_trig=True): centre of the reference's module-global scratch rect, [N,2] fp64 -- e.g. the
         `state_inner[..., :2]` a golden trajectory dumped (include/roborugby_amd.h: rr_set_scratch_rect)."""
         xy = torch.as_tensor(xy, dtype=torch.float64, device=self.device).contiguous().view(self.num_envs, 2)
-        _lib.check(self._lib.rr_set_scratch_rect(self._h, _ptr(xy), self._stream()), "rr_set_scratch_rect")
+        _lib.check(self._lib.rr_set_scratch_rect(self._h, _ptr(xy), self._stream()), "rr_set_scratch_rect", self._lib)
         torch.cuda.current_stream(self.device).synchronize()
 
     def get_scratch_rect(self):
         xy = self._new((self.num_envs, 2), torch.float64)
-        _lib.check(self._lib.rr_get_scratch_rect(self._h, _ptr(xy), self._stream()), "rr_get_scratch_rect")
+        _lib.check(self._lib.rr_get_scratch_rect(self._h, _ptr(xy), self._stream()), "rr_get_scratch_rect", self._lib)
         return xy
 
     def get_episode_state(self):
@@ -414,14 +430,32 @@ class BatchedRoboRugbyEnv:
         reset RNG: without it a resumed run would replay the placements of episodes 1, 2, ...), steps in the running
         episode, finished episodes, last episode's length, fault flag; `acc` [N,4] = running / last finished returns."""
         ints, acc = self._new((self.num_envs, 5), torch.int32), self._new((self.num_envs, 4), torch.float64)
-        _lib.check(self._lib.rr_get_episode_state(self._h, _ptr(ints), _ptr(acc), self._stream()), "rr_get_episode_state")
+        _lib.check(self._lib.rr_get_episode_state(self._h, _ptr(ints), _ptr(acc), self._stream()), "rr_get_episode_state", self._lib)
         return dict(ints=ints, acc=acc)
 
     def set_episode_state(self, ints, acc):
         ints = torch.as_tensor(ints, dtype=torch.int32, device=self.device).contiguous().view(self.num_envs, 5)
         acc = torch.as_tensor(acc, dtype=torch.float64, device=self.device).contiguous().view(self.num_envs, 4)
-        _lib.check(self._lib.rr_set_episode_state(self._h, _ptr(ints), _ptr(acc), self._stream()), "rr_set_episode_state")
+        _lib.check(self._lib.rr_set_episode_state(self._h, _ptr(ints), _ptr(acc), self._stream()), "rr_set_episode_state", self._lib)
         torch.cuda.current_stream(self.device).synchronize()
+
+    def checkpoint_state(self):
+        """Everything a resumed run needs besides the agent: `env_state` (get_state), `episode` (get_episode_state: the episode index
+        keys the reset RNG) and, for the parity build, `scratch_rect` (the reference's module-global rect, part of its state).
+        Budgeted mode: take it only after a call in which no row was NOT_READY (set_step_budget(0) + one step() guarantees that):
+        rr_set_state on resume clears a parked step, i.e. would drop the rest of that step and the action the arena accepted."""
+        ck = dict(env_state=self.get_state(), episode=self.get_episode_state())
+        if self.exact_trig:
+            ck["scratch_rect"] = self.get_scratch_rect()
+        return ck
+
+    def load_checkpoint_state(self, ck):
+        st = ck["env_state"]
+        self.set_state(st["robots"], st["robots_i"], st["balls"], st["step"])
+        if "episode" in ck:
+            self.set_episode_state(ck["episode"]["ints"], ck["episode"]["acc"])
+        if self.exact_trig and "scratch_rect" in ck:
+            self.set_scratch_rect(ck["scratch_rect"])
 
     def set_state(self, robots, robots_i, balls, step):
         p, N = self.preset, self.num_envs
@@ -430,23 +464,27 @@ class BatchedRoboRugbyEnv:
         balls = torch.as_tensor(balls, dtype=torch.float64, device=self.device).contiguous().view(N, p.nb, 8)
         step = torch.as_tensor(step, dtype=torch.int32, device=self.device).contiguous().view(N)
         _lib.check(self._lib.rr_set_state(self._h, _ptr(robots), _ptr(robots_i), _ptr(balls), _ptr(step), self._stream()),
-                   "rr_set_state")
+                   "rr_set_state", self._lib)
         torch.cuda.current_stream(self.device).synchronize()  # inputs may be temporaries
+        if self._bout is not None:
+            self._seed_bout()
 
     def set_poses(self, robots_xyr, balls_xyv):
         """The reference's lst_starting_config (RR_EnvBase.py:35-52) per arena, plus ball velocities."""
         p, N = self.preset, self.num_envs
         r = torch.as_tensor(robots_xyr, dtype=torch.float64, device=self.device).contiguous().view(N, p.nr, 3)
         b = torch.as_tensor(balls_xyv, dtype=torch.float64, device=self.device).contiguous().view(N, p.nb, 4)
-        _lib.check(self._lib.rr_set_poses(self._h, _ptr(r), _ptr(b), self._stream()), "rr_set_poses")
+        _lib.check(self._lib.rr_set_poses(self._h, _ptr(r), _ptr(b), self._stream()), "rr_set_poses", self._lib)
         torch.cuda.current_stream(self.device).synchronize()
+        if self._bout is not None:
+            self._seed_bout()
 
     def goal_scores(self):
         """Goal.get_score() of (happy, grumpy) goal (RR_Goal.py:87-88): identically 0 on the live path -- the reference
         never feeds its goal bookkeeping, so `done` is purely the step counter -- unless the env was
         built with goal_scoring=True (the opt-in extension): then 500 x (positive - negative balls the goal has consumed)."""
         s = self._new((self.num_envs, 2), torch.int32)
-        _lib.check(self._lib.rr_goal_scores(self._h, _ptr(s), self._stream()), "rr_goal_scores")
+        _lib.check(self._lib.rr_goal_scores(self._h, _ptr(s), self._stream()), "rr_goal_scores", self._lib)
         return s
 
     def episode_stats(self):
@@ -455,17 +493,17 @@ class BatchedRoboRugbyEnv:
         lr, lrg = self._new((N,), torch.float32), self._new((N,), torch.float32)
         ll, cnt = self._new((N,), torch.int32), self._new((N,), torch.int32)
         _lib.check(self._lib.rr_episode_stats(self._h, _ptr(lr), _ptr(lrg), _ptr(ll), _ptr(cnt), self._stream()),
-                   "rr_episode_stats")
+                   "rr_episode_stats", self._lib)
         return lr, lrg, ll, cnt
 
     def lanes_per_env(self):
         v = C.c_int32()
-        _lib.check(self._lib.rr_lanes_per_env(self._h, C.byref(v)), "rr_lanes_per_env")
+        _lib.check(self._lib.rr_lanes_per_env(self._h, C.byref(v)), "rr_lanes_per_env", self._lib)
         return v.value
 
     def state_bytes_per_env(self):
         b = C.c_int64()
-        _lib.check(self._lib.rr_state_bytes_per_env(self._h, C.byref(b)), "rr_state_bytes_per_env")
+        _lib.check(self._lib.rr_state_bytes_per_env(self._h, C.byref(b)), "rr_state_bytes_per_env", self._lib)
         return b.value
 
 

@@ -31,5 +31,5 @@ def chase(env, obs, step=0, noise=0.1, seed=0, na=None, step_of=None, out=None):
     so = C.c_void_p(step_of.data_ptr()) if step_of is not None else None
     _lib.check(env._lib.rr_policy_chase(env._h, C.c_void_p(obs.data_ptr()), so, int(step) & 0xFFFFFFFF, float(noise), int(seed),
                                         C.c_void_p(out.data_ptr()), na, C.c_void_p(torch.cuda.current_stream(env.device).cuda_stream)),
-               "rr_policy_chase")
+               "rr_policy_chase", env._lib)
     return out

@@ -216,3 +216,48 @@ def test_hbm_copy_probe_copies():
     torch.cuda.synchronize()
     assert torch.equal(dst, src)
     assert lib.rr_probe_hbm_copy(C.c_void_p(dst.data_ptr() + 4), C.c_void_p(src.data_ptr()), C.c_size_t(64), None) == -1
+
+
+@pytest.mark.parametrize("preset", ["T", "G"])
+def test_not_ready_rows_keep_the_previous_observation_through_the_default_outputs(preset):
+    """step() with out=None hands out persistent buffers in the budgeted mode, and a row whose arena parks in the FIRST
+    call after construction / reset() / set_state() / set_step_budget() must read as the arena's previous observation (both teams),
+    not as zeros.  Budget = 1 clock on the stuck chase arenas: every one of them parks in its first call."""
+    import roborugby_amd as rr
+    d = np.load(os.path.join(HERE, "data", f"stuck_chase_{preset}.npz"))
+    n = len(d["step"])
+    acts = torch.as_tensor(d["actions"], device="cuda").to(torch.int32)
+
+    def first_call(env, what):
+        prev_h = env.get_game_state(1).clone()
+        prev_g = env.get_game_state(-1).clone() if env.has_grumpy else None
+        obs, rew, done, info = env.step(acts)
+        nr = (info.status & NOT_READY) != 0
+        assert int(nr.sum()) >= n // 2, (what, int(nr.sum()))  # the stuck arenas do park at a 1-clock budget
+        assert torch.equal(obs[nr], prev_h[nr]), what
+        assert float(obs[nr].abs().sum()) > 0.0
+        assert not bool(done[nr].any()) and float(rew[nr].abs().sum()) == 0.0
+        if prev_g is not None:
+            assert torch.equal(info.adblGrumpyState[nr], prev_g[nr]), what
+        # the parked arenas finish in later calls, with the observation of the step they accepted
+        for _ in range(200):
+            obs, rew, done, info = env.step(acts)
+            if not bool(((info.status & NOT_READY) != 0).any()):
+                break
+        assert not bool(((info.status & NOT_READY) != 0).any())
+
+    # (a) budget at construction, state written from outside
+    env = rr.BatchedRoboRugbyEnv(n, preset=preset, seed=3, time_limit=False, auto_reset=False, step_budget_clocks=1)
+    env.set_state(d["robots"], d["robots_i"], d["balls"], d["step"])
+    first_call(env, "constructor + set_state")
+    # (b) after a masked reset of half of the arenas followed by set_state of all (the rows not reset keep theirs)
+    env.reset(mask=torch.arange(n, device="cuda") % 2 == 0)
+    env.set_state(d["robots"], d["robots_i"], d["balls"], d["step"])
+    first_call(env, "masked reset + set_state")
+    env.close()
+    # (c) budget switched on later
+    env = rr.BatchedRoboRugbyEnv(n, preset=preset, seed=3, time_limit=False, auto_reset=False)
+    env.set_state(d["robots"], d["robots_i"], d["balls"], d["step"])
+    env.set_step_budget(1)
+    first_call(env, "set_step_budget")
+    env.close()

@@ -167,3 +167,44 @@ def test_fused_store_transition_equals_the_pytorch_path():
         assert a1.mem_cntr == a2.mem_cntr
     for name in ("state_memory", "new_state_memory", "action_memory", "reward_memory", "terminal_memory"):
         assert torch.equal(getattr(a1, name), getattr(a2, name)), name
+
+
+def test_checkpoint_round_trips_between_fused_and_torch_adam():
+    """a checkpoint written by the fused agent must resume under fused=False (and the other way round) with the same Adam
+    moments and step count, not with zero moments -- and it carries the epsilon-draw counter.  Three updates in one mode, checkpoint,
+    load into the other mode: the moments agree entry by entry, and one more update on the same rows moves both agents alike."""
+    import ctypes as C
+    from roborugby_amd import _lib
+    batch = 4096
+    for src_fused in (True, False):
+        src, g = _agent(batch, seed=5, fused=src_fused, use_graph=False)
+        dst, _ = _agent(batch, seed=6, fused=not src_fused, use_graph=False)
+        for _ in range(3):
+            src.learn()
+        src.choose_action(src.state_memory[:1024])
+        torch.cuda.synchronize()
+        sd = src.state_dict()
+        assert sd["act_calls"] == src._act_calls and "fused_adam" in sd and len(sd["optimizer"]["state"]) == 6
+        assert sd["fused_adam"]["step"] == 3 and int(torch.as_tensor(sd["optimizer"]["state"][0]["step"]).item()) == 3
+        dst.load_state_dict(sd)
+        assert dst._act_calls == src._act_calls
+        # same Adam state on both sides, in the destination's own representation
+        flat_src = sd["fused_adam"]
+        flat_dst = dst._fused_adam() if dst.fused else dst._flat_from_torch_adam(dst.Q_eval.optimizer.state_dict())
+        assert flat_dst["step"] == 3
+        assert torch.equal(flat_dst["exp_avg"].cpu(), flat_src["exp_avg"].cpu()) and torch.equal(flat_dst["exp_avg_sq"].cpu(), flat_src["exp_avg_sq"].cpu())
+        assert float(flat_src["exp_avg_sq"].max()) > 0.0
+        for p, q in zip(src.Q_eval.parameters(), dst.Q_eval.parameters()):
+            assert torch.equal(p, q)
+        # one more step on identical rows (same replay contents, same sampler state) in both modes
+        dst.state_memory.copy_(src.state_memory); dst.new_state_memory.copy_(src.new_state_memory); dst.action_memory.copy_(src.action_memory)
+        dst.reward_memory.copy_(src.reward_memory); dst.terminal_memory.copy_(src.terminal_memory)
+        dst.gen.set_state(src.gen.get_state())
+        src.learn(); dst.learn()
+        torch.cuda.synchronize()
+        for (k, p), q in zip(src.Q_eval.named_parameters(), dst.Q_eval.parameters()):
+            d = (p - q).abs()
+            assert float(d.max()) <= 2.5 * src._lr, (src_fused, k, float(d.max()))  # (an entry with a ~0 gradient may step differently)
+            assert float(torch.quantile(d.flatten()[:1_000_000], 0.999)) <= 2e-6, (src_fused, k)
+        src.close(); dst.close()
+        assert src._fused_h is None and dst._fused_h is None

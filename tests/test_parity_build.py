@@ -39,7 +39,7 @@ def _full_episodes(golden_dir, preset):
     return t, np.nonzero(na_used == na_used.max())[0], int(na_used.max())
 
 
-@pytest.mark.parametrize("preset,want", [("T", 13), ("G", 11), ("D", 8)])
+@pytest.mark.parametrize("preset,want", [("T", (4, 14)), ("G", (2, 12)), ("D", (1, 9))])
 def test_parity_build_follows_whole_golden_episodes_bit_for_bit(golden_dir, preset, want):
     t, full, na = _full_episodes(golden_dir, preset)
     fast = [ad.free_run(lambda: el.EmuEnv(preset, exact=False), t, ep, na) for ep in full]
@@ -47,7 +47,7 @@ def test_parity_build_follows_whole_golden_episodes_bit_for_bit(golden_dir, pres
     n_fast, n_exact = sum(x is None for x in fast), sum(x is None for x in exact)
     print(f"[{preset}] free-running golden episodes bit-identical to the reference to their last step: default build {n_fast}, parity build "
           f"{n_exact} of {len(full)}; first departures (parity build): {[x for x in exact if x is not None]}")
-    assert n_exact >= want and n_exact > n_fast
+    assert (n_fast, n_exact) == want  # the counts of round 3, on the emulation and on the MI355X alike: exact
 
 
 @pytest.mark.parametrize("preset", ["T", "G", "D"])
