@@ -1,23 +1,24 @@
-// rr_sim.hpp -- wave-per-arena lockstep simulator core for gfx950 (CDNA4).
+// rr_sim.hpp -- the phases of the batched lockstep simulator for gfx950 (CDNA4): GameEnv.step of RoboRugby's SimpleDuel3.
 //
-// One 64-lane wavefront owns one arena.  The arena's persistent record (SoA over entities) is
-// pulled from HBM into the wave's LDS slice with coalesced loads, the 12 physics sub-steps of
-// GameEnv.step (reference RR_EnvBase.py:275-287) run out of LDS, and the record is written back.
-// Inside a sub-step the all-pairs contact sweeps are spread over lanes (one lane per
-// (pair, side, side) or (ball, robot, diameter) task) and reduced with a wavefront ballot; the
-// contact RESPONSES mutate state that the next response reads (RR_EnvBase.py:373-388), so they are
-// applied in the reference's list order by wave-uniform code that walks the ballot mask.
+// A 64-lane wavefront is cut into 64 / VW "virtual waves" of VW lanes and each of them owns one arena (VW = 8 for the 2+2 / 4+4
+// shape, 2 for the 1+0 / 1+0 training shape: one lane per entity and nothing idle; VW = 64 is literally one wavefront per arena).
+// The arena's persistent record (SoA over entities) is pulled from HBM into its slice of LDS with lane-strided loads, the 12
+// physics sub-steps of GameEnv.step (reference RR_EnvBase.py:275-287) run out of LDS, and the record is written back.  A sub-step
+// is two fused lane-parallel phases (hooks + moves + broad phase | roll + broad phase) on the common, contact-free path; the
+// reference-shaped loops run only when a ballot reports something close: narrow phases one lane per (pair, diameter, side),
+// hits reduced with the arena's share of the wavefront ballot, and the contact RESPONSES -- which mutate state the next response
+// reads (RR_EnvBase.py:373-388) -- applied in the reference's list order per entity: bounces of different balls side by side in
+// slots of lanes, each response on a lane pair (x | y component, first | second chain; "lane pairs" below).
 //
-// The source is written against three tiny macros (RR_FOR_LANES / RR_SYNC / RR_VOTE) so that the
-// very same phases can also be compiled by g++ as a lane loop: tests/emu builds that variant to
-// debug the phase logic against the CPU oracle without a GPU.  It is a test harness only -- the
-// product library is the HIP build and nothing else.
+// The source is written against a few macros (RR_FOR_LANES / RR_FOR_PAIRS / RR_SYNC / RR_VOTE / RR_LANE_VAR / RR_XOR1) so that the
+// very same phases also compile with g++ as lane loops: tests/emu builds that variant to check the phase logic against the CPU
+// oracle without a GPU.  It is a test harness only -- the product library is the HIP build and nothing else.
 //
-// Real = double is the parity mode (the reference computes in Python floats = fp64); Real = float
-// is the fast mode.  Incremental edge bookkeeping (MyUtils.py:141-148), int-truncated wall rects
-// (RR_Ball.py:8-15) and Python's float-% are reproduced so that knife-edge branches agree with the
-// reference; the only deliberate deviations are the ~1e-13 "copy()" and module-global scratch-rect
-// noises listed in DESIGN.md.
+// Real = double is the parity mode (the reference computes in Python floats = fp64); Real = float is the fast mode.  Incremental
+// edge bookkeeping (MyUtils.py:141-148), int-truncated wall rects (RR_Ball.py:8-15), Python's float %, FloatRect.copy()'s
+// re-derived centres and the list order of the responses are reproduced so that knife-edge branches agree with the reference.
+// The default build deviates from it in two places -- its own sin / cos (< 1 ulp) and the scratch rect placed exactly on the
+// ball -- which the parity build (-DRR_EXACT_TRIG=1: double-double sin / cos + the scratch-rect carry) removes; DESIGN.md section 2.
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
@@ -1427,6 +1428,400 @@ template <class C> RR_HDN void bounce_ball_off_bot(Arena<C> &A, const SimParams<
     RR_SYNC();
     RR_STAMP(25);
 }
+// ------------------------------------------------------------------------------------------------ lane pairs
+// A contact response is a chain of a few hundred dependent fp64 instructions, and one wavefront alone on its SIMD issues an fp64
+// instruction every 8 cycles however many of its lanes are active: a stuck arena's step is that instruction count (profiles/r03/
+// stuck_arena_phases_*.txt).  Most of a response is the same arithmetic on an x and on a y component, and where it is not it is two
+// independent chains (the slope of the diameter | of the prior-frame side, the intersection with the side | with the prior-frame
+// side, the distance of the intersection from one end point | from the other).  So a response runs on a PAIR of lanes -- the even
+// lane takes the x component / the first chain, the odd lane the y component / the second -- and the two swap values through DPP
+// (RR_XOR1's instruction): the same operations on the same operands in the same order as RR_TrashyPhysics.py:155-245, about
+// half the instructions.  PV<R> is "one value per lane of the pair": ONE register on the GPU; the host emulation carries both lanes'
+// values and runs a pair phase once per pair (RR_FOR_PAIRS), so the very same source is checked against the oracle on the CPU.
+#if RR_GPU
+#define RR_PV_N 1
+#define RR_FOR_PAIRS(l) RR_FOR_LANES(l)
+#define RR_PV_ROLE(l, i) ((l) & 1)
+#define RR_PVLOAD(name, l) (rr::PV<R>{ { name } })
+#define RR_PVSTORE(name, l, val) (name) = (val).v[0]
+#else
+#define RR_PV_N 2
+#define RR_FOR_PAIRS(l) for (int l = 0; l < C::VW; l += 2)
+#define RR_PV_ROLE(l, i) (i)
+#define RR_PVLOAD(name, l) (rr::PV<R>{ { name[l], name[(l) + 1] } })
+#define RR_PVSTORE(name, l, val) do { name[l] = (val).v[0]; name[(l) + 1] = (val).v[1]; } while (0)
+#endif
+#define RR_PV_EACH(i) for (int i = 0; i < RR_PV_N; i++)
+template <typename R> struct PV { R v[RR_PV_N]; };
+// the partner lane's value
+template <typename R> RR_HD PV<R> pv_swap(PV<R> a) {
+#if RR_GPU
+    PV<R> r = { { lane_xor1(a.v[0]) } };
+#else
+    PV<R> r = { { a.v[1], a.v[0] } };
+#endif
+    return r;
+}
+// the even (role 0) / odd (role 1) lane's value on both lanes
+template <typename R> RR_HD PV<R> pv_from0(PV<R> a, int l) {
+#if RR_GPU
+    const R o = lane_xor1(a.v[0]);
+    PV<R> r = { { (l & 1) ? o : a.v[0] } };
+#else
+    (void)l;
+    PV<R> r = { { a.v[0], a.v[0] } };
+#endif
+    return r;
+}
+template <typename R> RR_HD PV<R> pv_from1(PV<R> a, int l) {
+#if RR_GPU
+    const R o = lane_xor1(a.v[0]);
+    PV<R> r = { { (l & 1) ? a.v[0] : o } };
+#else
+    (void)l;
+    PV<R> r = { { a.v[1], a.v[1] } };
+#endif
+    return r;
+}
+// element p of a pair of arrays that sit `stride` apart (x fields and y fields of the record are declared back to back): the lane of role p
+template <typename R> RR_HD PV<R> pv_ld2(const R *base, int stride, int idx, int l) {
+#if RR_GPU
+    PV<R> r = { { base[(l & 1) * stride + idx] } };
+#else
+    (void)l;
+    PV<R> r = { { base[idx], base[stride + idx] } };
+#endif
+    return r;
+}
+template <typename R> RR_HD void pv_st2(R *base, int stride, int idx, int l, PV<R> val) {
+#if RR_GPU
+    base[(l & 1) * stride + idx] = val.v[0];
+#else
+    (void)l;
+    base[idx] = val.v[0]; base[stride + idx] = val.v[1];
+#endif
+}
+
+// ---- concurrent ball-robot bounces of one resolve pass (RR_EnvBase.py:380-384: `for ball, bot in collisions: bounce_ball_off_bot`)
+// The hit list is ball-major and a bounce reads the robot (which stands still inside the resolve loop) and reads / writes ITS
+// ball only: bounces of DIFFERENT balls are independent, bounces of one ball keep their list order.  So every ball with a hit gets
+// a SLOT of G = 8, 4 or 2 lanes of its arena (the more balls, the narrower) and walks its own robots in order, all slots side
+// by side; a slot keeps its ball in registers across its bounces (component p of centre / edges / velocity in the lanes of role p)
+// and writes it back once.  Inside a slot the surface search spreads its eight (side, diameter) candidates over the G lanes -- the
+// slot's share of the arena's ballot, lowest candidate first = the reference's first hit -- and the response runs on lane pairs.
+// Parity build: the scratch rect makes every response depend on the previous one (carry_response), so the caller hands over one
+// pair at a time; the response arithmetic is shared.
+template <class C> struct PairFields {
+    using R = typename C::Real;
+    using P = typename ArenaBody<C>::P;
+    static constexpr int NR = C::NR, NB = C::NB;
+    static_assert(offsetof(P, rcy) == offsetof(P, rcx) + NR * sizeof(R), "rcx, rcy back to back");
+    static_assert(offsetof(P, py) == offsetof(P, px) + NR * sizeof(R), "px, py back to back");
+    static_assert(offsetof(P, bcy) == offsetof(P, bcx) + NB * sizeof(R), "bcx, bcy back to back");
+    static_assert(offsetof(P, bt) == offsetof(P, bl) + 2 * NB * sizeof(R) && offsetof(P, bb) == offsetof(P, brt) + 2 * NB * sizeof(R), "bl brt bt bb");
+    static_assert(offsetof(P, bvy) == offsetof(P, bvx) + NB * sizeof(R), "bvx, bvy back to back");
+    static_assert(offsetof(ArenaBody<C>, ay) == offsetof(ArenaBody<C>, ax) + NR * sizeof(R), "ax, ay back to back");
+    static_assert(offsetof(ArenaBody<C>, pfy) == offsetof(ArenaBody<C>, pfx) + NB * sizeof(R), "pfx, pfy back to back");
+};
+// RR_TrashyPhysics.py:192-204 on a lane pair: con / v hold component p; returns d2 on both lanes
+template <typename R> RR_HD PV<R> pv_bounce_reflect(PV<R> con, PV<R> &v) {
+    PV<R> sq, pr, d2, num;
+    RR_PV_EACH(i) { sq.v[i] = con.v[i] * con.v[i]; pr.v[i] = con.v[i] * v.v[i]; }
+    const PV<R> sqo = pv_swap(sq), pro = pv_swap(pr);
+    RR_PV_EACH(i) {
+        d2.v[i] = sq.v[i] + sqo.v[i];   // con.x^2 + con.y^2 (IEEE addition commutes: both lanes hold the same bits)
+        num.v[i] = pr.v[i] + pro.v[i];  // con.x vx + con.y vy
+        const R term = num.v[i] / d2.v[i];
+        const R prj = term * con.v[i];
+        if ((prj < (R)0 && con.v[i] > (R)0) || (prj > (R)0 && con.v[i] < (R)0)) v.v[i] = -prj * (R).8 * (R).8;
+    }
+    return d2;
+}
+// rectDblPriorFrame of robot r on a lane pair (see robot_prev_frame): centre component p, and component p of the TL / TR corner offsets
+template <class C>
+RR_HD void pv_robot_prev_frame(const Arena<C> &A, const SimParams<typename C::Real> &sp, int r, uint32_t bots_moved, int l,
+                               PV<typename C::Real> &q, PV<typename C::Real> &tl, PV<typename C::Real> &tr) {
+    using R = typename C::Real;
+    const PV<R> rc = pv_ld2<R>(&A.p.rcx[0], C::NR, r, l);
+    PV<R> cc;
+    RR_PV_EACH(i) { const R K = RR_PV_ROLE(l, i) ? (R)20 : (R)10; cc.v[i] = K + (rc.v[i] - K); }
+    R rot;
+    if (bots_moved & (1u << r)) {
+        const PV<R> a = pv_ld2<R>(&A.ax[0], C::NR, r, l);
+        RR_PV_EACH(i) q.v[i] = cc.v[i] + (a.v[i] - cc.v[i]);
+        rot = A.arot[r];
+    } else if (!is_nan(A.p.px[r])) {
+        const PV<R> a = pv_ld2<R>(&A.p.px[0], C::NR, r, l);
+        RR_PV_EACH(i) q.v[i] = cc.v[i] + (a.v[i] - cc.v[i]);
+        rot = A.p.prot[r];
+    } else {
+        q = cc;
+        rot = A.p.rrot[r];
+    }
+    const R nr = norm360<R>(rot);
+    if (nr == A.p.rrot[r]) {
+        tl = pv_ld2<R>(&A.rel[r][0], 1, 0, l); tr = pv_ld2<R>(&A.rel[r][2], 1, 0, l);
+    } else {
+        R rel[8];
+        corners_for<R>(nr, (R)10, (R)20, sp.rob_cdist, rel);
+        RR_PV_EACH(i) { const int p = RR_PV_ROLE(l, i); tl.v[i] = p ? rel[1] : rel[0]; tr.v[i] = p ? rel[3] : rel[2]; }
+    }
+}
+template <typename R> RR_HD R pv_prev_off(int c, R tl, R tr) { return (c == TL) ? tl : (c == TR) ? tr : (c == BL) ? -tr : -tl; } // BR = -TL, BL = -TR
+#ifndef RR_NO_CBR
+#define RR_CBR 1
+#else
+#define RR_CBR 0 // A/B builds only: the resolve pass applies its ball-robot bounces one after the other (bounce_ball_off_bot)
+#endif
+template <class C>
+RR_HDN void bounce_pass(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t br, uint32_t bots_moved, int &st) {
+    using R = typename C::Real;
+    constexpr int NR = C::NR, NB = C::NB, VW = C::VW;
+    static_assert(VW >= 2 && (VW & 1) == 0, "lane pairs");
+    (void)sizeof(PairFields<C>);
+    constexpr uint32_t RM = (1u << NR) - 1u;
+    constexpr int MAXS = NB < VW / 2 ? NB : VW / 2; // slots of one round
+    uint32_t hb = 0;
+    for (int b = 0; b < NB; b++) hb |= ((br >> (b * NR)) & RM) ? (1u << b) : 0u;
+    RR_LANE_VAR(int, s_b);        // the slot's ball (-1: the lane has no slot)
+    RR_LANE_VAR(uint32_t, s_rm);  // its robots still to bounce off, list order = ascending
+    RR_LANE_VAR(R, s_c); RR_LANE_VAR(R, s_lo); RR_LANE_VAR(R, s_hi); RR_LANE_VAR(R, s_v); // component p of centre / low edge / high edge / velocity
+    RR_LANE_VAR(R, s_exc);
+    RR_LANE_VAR(R, s_dc);         // component p of the centre the diameters are built from (parity build: the carried scratch rect)
+    RR_LANE_VAR(int, s_go); RR_LANE_VAR(int, s_k); RR_LANE_VAR(int, s_cn); RR_LANE_VAR(int, s_st);
+    RR_LANE_VAR(R, s_md); RR_LANE_VAR(R, s_cd); // slope / intercept of this lane's diameter (its candidates share it: the lane's d is fixed)
+    RR_T0();
+#pragma unroll 1
+    while (hb) { // one round, unless more balls were hit than the arena has lane pairs
+        const int nhb = __builtin_popcount(hb);
+        const int lgG = (VW >= 8 && nhb * 8 <= VW) ? 3 : (VW >= 4 && nhb * 4 <= VW) ? 2 : 1;
+        const int G = 1 << lgG;
+        const int nsl = nhb < (VW >> lgG) ? nhb : (VW >> lgG);
+        uint32_t rest = hb;
+        for (int s = 0; s < MAXS; s++) rest = (s < nsl) ? (rest & (rest - 1)) : rest;
+        RR_FOR_LANES(l) {
+            const int slot = l >> lgG, p = l & 1;
+            uint32_t m = hb;
+            for (int s = 0; s < MAXS; s++) m = (s < slot) ? (m & (m - 1)) : m;
+            const bool on = slot < nsl;
+            const int b = on ? low_bit(m | (1u << 31)) : 0;
+            RR_LV(s_b, l) = on ? b : -1;
+            RR_LV(s_rm, l) = on ? ((br >> (b * NR)) & RM) : 0u;
+            RR_LV(s_c, l) = (&A.p.bcx[0])[p * NB + b];
+            RR_LV(s_lo, l) = (&A.p.bl[0])[p * 2 * NB + b];
+            RR_LV(s_hi, l) = (&A.p.brt[0])[p * 2 * NB + b];
+            RR_LV(s_v, l) = (&A.p.bvx[0])[p * NB + b];
+            RR_LV(s_exc, l) = A.exc[b];
+            RR_LV(s_st, l) = 0;
+        }
+        hb = rest;
+#pragma unroll 1
+        for (;;) {
+            uint64_t any = 0;
+            RR_FOR_LANES(l) { RR_VOTE(any, l, RR_LV(s_rm, l) != 0u); }
+            if (!any) break;
+            // ---- this bounce: a no-op for a ball at rest (:156); else where do the diameters sit
+            RR_FOR_LANES(l) {
+                const R vo = RR_XOR1(s_v, l);
+                RR_LV(s_go, l) = (RR_LV(s_rm, l) != 0u && !(RR_LV(s_v, l) == (R)0 && vo == (R)0)) ? 1 : 0;
+                RR_LV(s_k, l) = -1; RR_LV(s_cn, l) = -1;
+#if !RR_CARRY
+                RR_LV(s_dc, l) = RR_LV(s_c, l);
+#endif
+            }
+#if RR_CARRY
+            // `_rectBallInner.center = ball.center` (:165) is a relative move of the module-global rect (see "scratch-rect carry")
+            RR_FOR_LANES(l) {
+                if (RR_LV(s_go, l)) RR_LV(s_dc, l) = carry1<R>(A.p.ic[l & 1], RR_LV(s_c, l));
+            }
+            RR_SYNC();
+            RR_FOR_LANES(l) {
+                if (RR_LV(s_go, l) && (l & (G - 1)) < 2) A.p.ic[l & 1] = RR_LV(s_dc, l);
+            }
+            RR_SYNC();
+#endif
+            // ---- surface search (:180-186): candidate t = (side t >> 1, diameter t & 1), t = sub + G c in round c
+            RR_FOR_LANES(l) {
+                const R dco = RR_XOR1(s_dc, l);
+                if (RR_LV(s_go, l)) {
+                    const int r = low_bit(RR_LV(s_rm, l)), d = l & 1;
+                    const R dcx = (l & 1) ? dco : RR_LV(s_dc, l), dcy = (l & 1) ? RR_LV(s_dc, l) : dco;
+                    const R *q = A.u.irel[r];
+                    // (BL -> TR) for d = 0, (BR -> TL) for d = 1 (RR_TrashyPhysics.py:95-104)
+                    const V2<R> da = { dcx + q[2 * (d ? BR : BL)], dcy + q[2 * (d ? BR : BL) + 1] }, db = { dcx + q[2 * (d ? TL : TR)], dcy + q[2 * (d ? TL : TR) + 1] };
+                    int lst = 0;
+                    slope_yint<R>(da, db, RR_LV(s_md, l), RR_LV(s_cd, l), lst);
+                    RR_LV(s_st, l) |= lst;
+                }
+            }
+#pragma unroll 1
+            for (int c = 0; c < (8 >> lgG); c++) {
+                uint64_t m = 0;
+                RR_FOR_LANES(l) {
+                    bool hit = false;
+                    const R dco = RR_XOR1(s_dc, l);
+                    if (RR_LV(s_go, l) && RR_LV(s_k, l) < 0) {
+                        const int r = low_bit(RR_LV(s_rm, l)), t = (l & (G - 1)) + (c << lgG), sd = t >> 1, d = t & 1;
+                        const R dcx = (l & 1) ? dco : RR_LV(s_dc, l), dcy = (l & 1) ? RR_LV(s_dc, l) : dco;
+                        const R *q = A.u.irel[r];
+                        const Seg<R> di = { { dcx + q[2 * (d ? BR : BL)], dcy + q[2 * (d ? BR : BL) + 1] }, { dcx + q[2 * (d ? TL : TR)], dcy + q[2 * (d ? TL : TR) + 1] } };
+                        const Seg<R> side = robot_side(A, r, sd);
+                        if (lgG == 3 || boxes_meet<R>(side, di, (R)0)) { // (the pre-test pays where a lane sweeps several candidates)
+                            const V2<R> I = intersect_mb<R>(A.sm[r][sd], A.sc[r][sd], side.a.x, RR_LV(s_md, l), RR_LV(s_cd, l), di.a.x);
+                            hit = within<R>(I, side, (R)0) & within<R>(I, di, (R)0);
+                        }
+                    }
+                    RR_VOTE(m, l, hit);
+                }
+                RR_FOR_LANES(l) {
+                    const uint32_t bits = (uint32_t)(m >> (l & ~(G - 1))) & ((1u << G) - 1u); // this slot's share of the ballot
+                    if (RR_LV(s_go, l) && RR_LV(s_k, l) < 0 && bits) RR_LV(s_k, l) = (c << lgG) + low_bit(bits);
+                }
+            }
+            // ---- corner search (:219): first corner (TL, TR, BL, BR) closer to the ball centre than 7
+            uint64_t needc = 0;
+            RR_FOR_LANES(l) { RR_VOTE(needc, l, RR_LV(s_go, l) && RR_LV(s_k, l) < 0); }
+            if (RR_UNLIKELY(needc)) {
+                for (int c = 0; c < (G >= 4 ? 1 : 2); c++) {
+                    uint64_t m = 0;
+                    RR_FOR_LANES(l) {
+                        bool hit = false;
+                        const R co = RR_XOR1(s_c, l);
+                        const int t = (l & (G - 1)) + (c << lgG);
+                        if (RR_LV(s_go, l) && RR_LV(s_k, l) < 0 && RR_LV(s_cn, l) < 0 && t < 4) {
+                            const int r = low_bit(RR_LV(s_rm, l));
+                            const V2<R> bc = { (l & 1) ? co : RR_LV(s_c, l), (l & 1) ? RR_LV(s_c, l) : co };
+                            hit = dist<R>(robot_corner(A, r, t), bc) < (R)7;
+                        }
+                        RR_VOTE(m, l, hit);
+                    }
+                    RR_FOR_LANES(l) {
+                        const uint32_t bits = (uint32_t)(m >> (l & ~(G - 1))) & ((1u << G) - 1u);
+                        if (RR_LV(s_go, l) && RR_LV(s_k, l) < 0 && RR_LV(s_cn, l) < 0 && bits) RR_LV(s_cn, l) = (c << lgG) + low_bit(bits);
+                    }
+                }
+            }
+            RR_STAMP(23);
+            // ---- the response, on lane pairs
+            RR_FOR_PAIRS(l) {
+                const int k = RR_LV(s_k, l), cn = RR_LV(s_cn, l);
+                PV<R> c0 = RR_PVLOAD(s_c, l), v = RR_PVLOAD(s_v, l);
+                const PV<R> dc = RR_PVLOAD(s_dc, l);
+                const PV<R> dco = pv_swap(dc);
+                if (RR_LV(s_go, l) && (k >= 0 || cn >= 0)) {
+                    const int r = low_bit(RR_LV(s_rm, l)), b = RR_LV(s_b, l);
+                    PV<R> pvq, ptl, ptr;
+                    pv_robot_prev_frame(A, sp, r, bots_moved, l, pvq, ptl, ptr);
+                    const PV<R> pvqo = pv_swap(pvq), ptlo = pv_swap(ptl), ptro = pv_swap(ptr);
+                    PV<R> mv;
+                    if (k >= 0) {
+                        const int sd = k >> 1, d = k & 1, ca = side_a(sd), cb = side_b(sd);
+                        if ((l & (G - 1)) == 0) RR_TRACE("E bounce surface s=%d d=%d b=%d r=%d\n", sd, d, b, r);
+                        // role 0: the diameter (di.a, di.b); role 1: the prior-frame side (sprev.a, sprev.b) -- each lane its segment's slope
+                        PV<R> sax, say, sbx, sby, m, cc;
+                        RR_PV_EACH(i) {
+                            const int p = RR_PV_ROLE(l, i);
+                            const R dcx = p ? dco.v[i] : dc.v[i], dcy = p ? dc.v[i] : dco.v[i];
+                            const R qx = p ? pvqo.v[i] : pvq.v[i], qy = p ? pvq.v[i] : pvqo.v[i];
+                            const R tlx = p ? ptlo.v[i] : ptl.v[i], tly = p ? ptl.v[i] : ptlo.v[i], trx = p ? ptro.v[i] : ptr.v[i], try_ = p ? ptr.v[i] : ptro.v[i];
+                            const R *q = A.u.irel[r];
+                            const int ea = d ? BR : BL, eb = d ? TL : TR;
+                            sax.v[i] = p ? qx + pv_prev_off<R>(ca, tlx, trx) : dcx + q[2 * ea];
+                            say.v[i] = p ? qy + pv_prev_off<R>(ca, tly, try_) : dcy + q[2 * ea + 1];
+                            sbx.v[i] = p ? qx + pv_prev_off<R>(cb, tlx, trx) : dcx + q[2 * eb];
+                            sby.v[i] = p ? qy + pv_prev_off<R>(cb, tly, try_) : dcy + q[2 * eb + 1];
+                            int lst = 0;
+                            const V2<R> a = { sax.v[i], say.v[i] }, bb_ = { sbx.v[i], sby.v[i] };
+                            slope_yint<R>(a, bb_, m.v[i], cc.v[i], lst);
+                            if (lst) RR_LV(s_st, l) |= lst;
+                        }
+                        const PV<R> md = pv_from0(m, l), cd = pv_from0(cc, l), dax = pv_from0(sax, l), day = pv_from0(say, l),
+                                    dbx = pv_from0(sbx, l), dby = pv_from0(sby, l);
+                        // role 0: I = side x diameter; role 1: Ip = prior-frame side x diameter
+                        PV<R> ix, iy;
+                        const Seg<R> side = robot_side(A, r, sd);
+                        RR_PV_EACH(i) {
+                            const int p = RR_PV_ROLE(l, i);
+                            const R m1 = p ? m.v[i] : A.sm[r][sd], b1 = p ? cc.v[i] : A.sc[r][sd], x1 = p ? sax.v[i] : side.a.x;
+                            const V2<R> I = intersect_mb<R>(m1, b1, x1, md.v[i], cd.v[i], dax.v[i]);
+                            ix.v[i] = I.x; iy.v[i] = I.y;
+                        }
+                        const PV<R> ipx = pv_from1(ix, l), ipy = pv_from1(iy, l), Ix = pv_from0(ix, l), Iy = pv_from0(iy, l);
+                        // role 0: da = dist(di.a, Ip); role 1: db = dist(di.b, Ip)
+                        PV<R> dd;
+                        RR_PV_EACH(i) {
+                            const int p = RR_PV_ROLE(l, i);
+                            const V2<R> e = { p ? dbx.v[i] : dax.v[i], p ? dby.v[i] : day.v[i] }, ip = { ipx.v[i], ipy.v[i] };
+                            dd.v[i] = dist<R>(e, ip);
+                        }
+                        const PV<R> da = pv_from0(dd, l), db = pv_from1(dd, l);
+                        PV<R> cp, con;
+                        RR_PV_EACH(i) {
+                            const int p = RR_PV_ROLE(l, i);
+                            const R ea_ = p ? day.v[i] : dax.v[i], eb_ = p ? dby.v[i] : dbx.v[i]; // component p of di.a / di.b
+                            cp.v[i] = (da.v[i] < db.v[i]) ? ea_ : eb_;
+                            const R opp = (da.v[i] >= db.v[i]) ? ea_ : eb_;
+                            con.v[i] = opp - cp.v[i];
+                        }
+                        const PV<R> d2 = pv_bounce_reflect<R>(con, v);
+                        RR_PV_EACH(i) {
+                            const int p = RR_PV_ROLE(l, i);
+                            const R sq = m_sqrt(d2.v[i]);
+                            mv.v[i] = ((p ? Iy.v[i] : Ix.v[i]) - cp.v[i]) + con.v[i] * (R).5 / sq;
+                        }
+                    } else {
+                        if ((l & (G - 1)) == 0) RR_TRACE("E bounce corner c=%d b=%d r=%d\n", cn, b, r);
+                        const PV<R> rc = pv_ld2<R>(&A.p.rcx[0], NR, r, l), ro = pv_ld2<R>(&A.rel[r][2 * cn], 1, 0, l);
+                        PV<R> con, pc, sq;
+                        RR_PV_EACH(i) {
+                            const R bcn = rc.v[i] + ro.v[i];
+                            pc.v[i] = pvq.v[i] + pv_prev_off<R>(cn, ptl.v[i], ptr.v[i]);
+                            con.v[i] = c0.v[i] - (bcn * (R)3 + pc.v[i]) / (R)4;
+                        }
+                        const PV<R> d2 = pv_bounce_reflect<R>(con, v);
+                        RR_PV_EACH(i) { const R df = c0.v[i] - pc.v[i]; sq.v[i] = df * df; }
+                        const PV<R> sqo = pv_swap(sq);
+                        RR_PV_EACH(i) {
+                            const R ex = m_sqrt(sq.v[i] + sqo.v[i]), cd = m_sqrt(d2.v[i]);
+                            mv.v[i] = con.v[i] * ex / cd;
+                        }
+                    }
+                    // `centerx += v` goes through the setter: the applied delta is (c + v) - c; the other axis' setter call adds 0 to this
+                    // axis' fields -- after this axis' own delta for x, before it for y (RR_TrashyPhysics.py:242-243, MyUtils.py:141-148)
+                    PV<R> lo = RR_PVLOAD(s_lo, l), hi = RR_PVLOAD(s_hi, l), exc = RR_PVLOAD(s_exc, l), ab;
+                    const PV<R> pf = pv_ld2<R>(&A.pfx[0], NB, b, l);
+                    RR_PV_EACH(i) {
+                        const int p = RR_PV_ROLE(l, i);
+                        const R n = c0.v[i] + mv.v[i], dl = n - c0.v[i];
+                        const R d1 = p ? (R)0 : dl, d2_ = p ? dl : (R)0;
+                        c0.v[i] = (c0.v[i] + d1) + d2_; lo.v[i] = (lo.v[i] + d1) + d2_; hi.v[i] = (hi.v[i] + d1) + d2_;
+                        ab.v[i] = m_abs(c0.v[i] - pf.v[i]);
+                    }
+                    const PV<R> abo = pv_swap(ab);
+                    RR_PV_EACH(i) { const R e = ab.v[i] + abo.v[i]; if (e > exc.v[i]) exc.v[i] = e; }
+                    RR_PVSTORE(s_c, l, c0); RR_PVSTORE(s_lo, l, lo); RR_PVSTORE(s_hi, l, hi); RR_PVSTORE(s_v, l, v); RR_PVSTORE(s_exc, l, exc);
+                }
+            }
+            RR_FOR_LANES(l) { RR_LV(s_rm, l) &= RR_LV(s_rm, l) - 1u; }
+            RR_STAMP(25);
+        }
+        // ---- the slots' balls go back to the arena: the first pair of a slot writes, role p its component's fields
+        uint64_t anyst = 0;
+        RR_FOR_LANES(l) {
+            const int b = RR_LV(s_b, l), p = l & 1;
+            if (b >= 0 && (l & (G - 1)) < 2) {
+                (&A.p.bcx[0])[p * NB + b] = RR_LV(s_c, l);
+                (&A.p.bl[0])[p * 2 * NB + b] = RR_LV(s_lo, l);
+                (&A.p.brt[0])[p * 2 * NB + b] = RR_LV(s_hi, l);
+                (&A.p.bvx[0])[p * NB + b] = RR_LV(s_v, l);
+                if (p == 0) A.exc[b] = RR_LV(s_exc, l);
+            }
+            RR_VOTE(anyst, l, (RR_LV(s_st, l) & ST_DIV0) != 0);
+        }
+        if (anyst) st |= ST_DIV0;
+        RR_SYNC();
+    }
+}
 // bounce_balls (RR_TrashyPhysics.py:248-316)
 template <class C> RR_HDN void bounce_balls(Arena<C> &A, int i, int j, int &st) {
     using R = typename C::Real;
@@ -1477,6 +1872,132 @@ template <class C> RR_HDN void bounce_balls(Arena<C> &A, int i, int j, int &st) 
         ball_exc_update(A, i); ball_exc_update(A, j);
     }
     RR_SYNC();
+}
+// The ball-ball bounces of one resolve pass (RR_EnvBase.py:373-378: `for ball1, ball2 in collisions: bounce_balls`), on lane pairs.
+// A bounce reads and writes its two balls only, so consecutive bounces of the (frozen, ordered) hit list that share no ball are
+// independent: the list is cut into maximal runs of mutually disjoint pairs, a run's bounces go side by side -- one lane pair
+// each -- and the runs follow each other in list order.  Inside a bounce the even lane holds the x components, the odd lane the y
+// components (bounce_balls above, operation for operation; the two projections t1 | t2 are one division on either lane).
+template <class C> RR_HDN void bounce_balls_pass(Arena<C> &A, uint64_t bbm, int &st) {
+    using R = typename C::Real;
+    constexpr int NB = C::NB, VW = C::VW;
+    (void)sizeof(PairFields<C>);
+    RR_LANE_VAR(int, s_i); RR_LANE_VAR(int, s_j); RR_LANE_VAR(int, s_st);
+#pragma unroll 1
+    while (bbm) {
+        // the next run: pairs in list order until one shares a ball with the run (or the lane pairs are used up)
+        uint32_t used = 0;
+        int nrun = 0;
+        uint64_t todo = bbm;
+        int ri[VW / 2], rj[VW / 2];
+        for (int q = 0; q < VW / 2; q++) { ri[q] = -1; rj[q] = -1; }
+#pragma unroll
+        for (int q = 0; q < VW / 2; q++) {
+            if (todo && nrun == q) {
+                int i, j;
+                pair_of<C>(low_bit(todo), NB, i, j);
+                const uint32_t two = (1u << i) | (1u << j);
+                if (!(used & two)) { used |= two; ri[q] = i; rj[q] = j; nrun = q + 1; todo &= todo - 1; }
+            }
+        }
+        bbm = todo;
+        RR_FOR_LANES(l) {
+            int i = -1, j = -1;
+#pragma unroll
+            for (int q = 0; q < VW / 2; q++) { i = ((l >> 1) == q) ? ri[q] : i; j = ((l >> 1) == q) ? rj[q] : j; } // by value: no dynamically indexed local array
+            RR_LV(s_i, l) = i; RR_LV(s_j, l) = j; RR_LV(s_st, l) = 0;
+        }
+        RR_FOR_PAIRS(l) {
+            const int i = RR_LV(s_i, l), j = RR_LV(s_j, l);
+            const int bi = i < 0 ? 0 : i, bj = j < 0 ? 0 : j;
+            const PV<R> c1 = pv_ld2<R>(&A.p.bcx[0], NB, bi, l), c2 = pv_ld2<R>(&A.p.bcx[0], NB, bj, l);
+            PV<R> eq;
+            RR_PV_EACH(k) eq.v[k] = (c1.v[k] == c2.v[k]) ? (R)1 : (R)0;
+            const PV<R> eqo = pv_swap(eq);
+            if (i >= 0) {
+                RR_TRACE("E bb %d %d (pair)\n", i, j);
+                if (eq.v[0] != (R)0 && eqo.v[0] != (R)0) { // "balls are in the EXACT same spot" (:250)
+                    RR_LV(s_st, l) |= ST_SAME_SPOT;
+                } else {
+                    PV<R> u, sq;
+                    RR_PV_EACH(k) { u.v[k] = c2.v[k] - c1.v[k]; sq.v[k] = u.v[k] * u.v[k]; }
+                    const PV<R> sqo = pv_swap(sq);
+                    int m1 = A.bmass[bi], m2 = A.bmass[bj];
+                    const int m1_0 = m1, m2_0 = m2;
+                    PV<R> n1 = c1, n2 = c2, a, a2, pr1, pr2;
+                    RR_PV_EACH(k) {
+                        const R d12 = m_sqrt(sq.v[k] + sqo.v[k]);
+                        const R rr_ = u.v[k] * (R)7 / d12;
+                        const R p1 = c1.v[k] + rr_, p2 = c2.v[k] - rr_;
+                        const R buffer = (R)1.1, h = (p2 - p1) / (R)2;
+                        if (m1_0 == m2_0) { n1.v[k] = c1.v[k] + h * buffer; n2.v[k] = c2.v[k] - h * buffer; }
+                        else if (m1_0 > m2_0) { n2.v[k] = c2.v[k] + (p1 - p2) * buffer; }
+                        else { n1.v[k] = c1.v[k] + (p2 - p1) * buffer; }
+                        // centre setters are incremental: new centre = c + (n - c)
+                        const R cc1 = c1.v[k] + (n1.v[k] - c1.v[k]), cc2 = c2.v[k] + (n2.v[k] - c2.v[k]);
+                        a.v[k] = cc2 - cc1;          // tplVect1to2
+                        a2.v[k] = a.v[k] * a.v[k];
+                    }
+                    if (m1_0 > m2_0) m2 = m1_0; else if (m1_0 < m2_0) m1 = m2_0;
+                    PV<R> v1 = pv_ld2<R>(&A.p.bvx[0], NB, bi, l), v2 = pv_ld2<R>(&A.p.bvx[0], NB, bj, l);
+                    RR_PV_EACH(k) { const R bneg = a.v[k] * (R)-1; pr1.v[k] = a.v[k] * v1.v[k]; pr2.v[k] = bneg * v2.v[k]; } // tplVect2to1 = -a
+                    const PV<R> a2o = pv_swap(a2), pr1o = pv_swap(pr1), pr2o = pv_swap(pr2);
+                    // the two projections: t1 on the even lane, t2 on the odd one -- one division instruction for both
+                    PV<R> tt;
+                    RR_PV_EACH(k) {
+                        const int p = RR_PV_ROLE(l, k);
+                        const R d2 = a2.v[k] + a2o.v[k];
+                        const R num = p ? (pr2.v[k] + pr2o.v[k]) : (pr1.v[k] + pr1o.v[k]);
+                        int lst = 0;
+                        tt.v[k] = div0<R>(num, d2, lst);
+                        if (lst) RR_LV(s_st, l) |= lst;
+                    }
+                    const PV<R> t1 = pv_from0(tt, l), t2 = pv_from1(tt, l);
+                    const PV<R> f1 = pv_ld2<R>(&A.bfx[0], NB, bi, l), f2 = pv_ld2<R>(&A.bfx[0], NB, bj, l);
+                    PV<R> c1n = c1, c2n = c2, lo1 = pv_ld2<R>(&A.p.bl[0], 2 * NB, bi, l), hi1 = pv_ld2<R>(&A.p.brt[0], 2 * NB, bi, l),
+                          lo2 = pv_ld2<R>(&A.p.bl[0], 2 * NB, bj, l), hi2 = pv_ld2<R>(&A.p.brt[0], 2 * NB, bj, l), ab1, ab2;
+                    const PV<R> pf1 = pv_ld2<R>(&A.pfx[0], NB, bi, l), pf2 = pv_ld2<R>(&A.pfx[0], NB, bj, l);
+                    RR_PV_EACH(k) {
+                        const int p = RR_PV_ROLE(l, k);
+                        const R bneg = a.v[k] * (R)-1;
+                        const R df = t1.v[k] * a.v[k] - t2.v[k] * bneg;
+                        R w1 = v1.v[k], w2 = v2.v[k];
+                        w1 -= df * (R).995; w2 += df * (R).995;
+                        const R g1 = f1.v[k], g2 = f2.v[k];
+                        if (g1 > (R)0) w1 = py_max<R>(w1, g1); else if (g1 < (R)0) w1 = py_min<R>(w1, g1);
+                        if (g2 > (R)0) w2 = py_max<R>(w2, g2); else if (g2 < (R)0) w2 = py_min<R>(w2, g2);
+                        v1.v[k] = w1; v2.v[k] = w2;
+                        // ball_shift(i, n1x - x1, 0); ball_shift(i, 0, n1y - y1): this axis' delta, and the other call's + 0 (after it for x, before for y)
+                        const R e1 = n1.v[k] - c1.v[k], e2 = n2.v[k] - c2.v[k];
+                        const R e1a = p ? (R)0 : e1, e1b = p ? e1 : (R)0, e2a = p ? (R)0 : e2, e2b = p ? e2 : (R)0;
+                        c1n.v[k] = (c1.v[k] + e1a) + e1b; lo1.v[k] = (lo1.v[k] + e1a) + e1b; hi1.v[k] = (hi1.v[k] + e1a) + e1b;
+                        c2n.v[k] = (c2.v[k] + e2a) + e2b; lo2.v[k] = (lo2.v[k] + e2a) + e2b; hi2.v[k] = (hi2.v[k] + e2a) + e2b;
+                        ab1.v[k] = m_abs(c1n.v[k] - pf1.v[k]); ab2.v[k] = m_abs(c2n.v[k] - pf2.v[k]);
+                    }
+                    const PV<R> ab1o = pv_swap(ab1), ab2o = pv_swap(ab2);
+                    pv_st2<R>(&A.p.bcx[0], NB, bi, l, c1n); pv_st2<R>(&A.p.bl[0], 2 * NB, bi, l, lo1); pv_st2<R>(&A.p.brt[0], 2 * NB, bi, l, hi1);
+                    pv_st2<R>(&A.p.bcx[0], NB, bj, l, c2n); pv_st2<R>(&A.p.bl[0], 2 * NB, bj, l, lo2); pv_st2<R>(&A.p.brt[0], 2 * NB, bj, l, hi2);
+                    pv_st2<R>(&A.p.bvx[0], NB, bi, l, v1); pv_st2<R>(&A.p.bvx[0], NB, bj, l, v2);
+                    RR_PV_EACH(k) {
+                        if (RR_PV_ROLE(l, k) == 0) {
+                            A.bmass[bi] = m1; A.bmass[bj] = m2;
+                            const R x1 = ab1.v[k] + ab1o.v[k], x2 = ab2.v[k] + ab2o.v[k];
+                            if (x1 > A.exc[bi]) A.exc[bi] = x1;
+                            if (x2 > A.exc[bj]) A.exc[bj] = x2;
+                        }
+                    }
+                }
+            }
+        }
+        uint64_t m_same = 0, m_div0 = 0;
+        RR_FOR_LANES(l) {
+            RR_VOTE(m_same, l, (RR_LV(s_st, l) & ST_SAME_SPOT) != 0);
+            RR_VOTE(m_div0, l, (RR_LV(s_st, l) & ST_DIV0) != 0);
+        }
+        if (m_same) st |= ST_SAME_SPOT;
+        if (m_div0) st |= ST_DIV0;
+        RR_SYNC();
+    }
 }
 // bounce_ball_off_wall (RR_TrashyPhysics.py:320-338) -- independent per ball, one lane each
 template <class C> RR_HD void bounce_ball_off_wall_lane(Arena<C> &A, const SimParams<typename C::Real> &sp, int b) {
@@ -1595,6 +2116,19 @@ RR_HDN int resolve_ball_collisions(Arena<C> &A, const SimParams<typename C::Real
         if (count > 10) { RR_TRACE("E resolve gave up\n"); return 0; }
         naughty = false;
         uint64_t bb = detect_ball_pairs(A);
+#if RR_CBR
+        if (bb) {
+            naughty = true;
+#pragma unroll 1
+            for (uint64_t todo = bb; todo; todo &= todo - 1) {
+                int i, j;
+                pair_of<C>(low_bit(todo), C::NB, i, j);
+                RR_TRACE("E pass %d bb %d %d\n", count, i, j);
+                hit.b |= (1u << i) | (1u << j);
+            }
+            bounce_balls_pass(A, bb, st);
+        }
+#else
 #pragma unroll 1
         for (uint64_t todo = bb; todo; todo &= todo - 1) {
             int i, j;
@@ -1604,10 +2138,26 @@ RR_HDN int resolve_ball_collisions(Arena<C> &A, const SimParams<typename C::Real
             naughty = true;
             bounce_balls(A, i, j, st);
         }
+#endif
         RR_STAMP(14);
         // caches already built in this sub-step (a hit in the push or in an earlier pass)?  then the cheap variant
         uint32_t br = A.sides_ok ? detect_ball_robot<C, true>(A, sp) : detect_ball_robot<C, false>(A, sp);
         RR_STAMP(15);
+#if RR_CBR
+        if (br) {
+            naughty = true;
+            for (int b = 0; b < C::NB; b++) {
+                const uint32_t rm = (br >> (b * C::NR)) & ((1u << C::NR) - 1u);
+                hit.r |= rm; hit.b |= rm ? (1u << b) : 0u;
+            }
+#if RR_CARRY
+#pragma unroll 1
+            for (uint32_t todo = br; todo; todo &= todo - 1) bounce_pass(A, sp, todo & (0u - todo), bots_moved, st); // one at a time: the scratch rect
+#else
+            bounce_pass(A, sp, br, bots_moved, st); // the bounces of different balls side by side
+#endif
+        }
+#else
 #pragma unroll 1
         for (uint32_t todo = br; todo; todo &= todo - 1) {
             const int p = low_bit(todo);
@@ -1615,6 +2165,7 @@ RR_HDN int resolve_ball_collisions(Arena<C> &A, const SimParams<typename C::Real
             hit.b |= 1u << (p / C::NR); hit.r |= 1u << (p % C::NR);
             bounce_ball_off_bot(A, sp, p % C::NR, p / C::NR, bots_moved, st);
         }
+#endif
         RR_STAMP(16);
         uint32_t bw = detect_ball_wall(A, sp);
         if (bw) {

@@ -156,15 +156,16 @@ def test_rccl_backend_itself_on_a_single_rank_group():
 
 
 # VERDICT r3 asked for an 8-process rehearsal on the one GPU.  The GPU boxes of this pool admit at most SIX processes on the card at
-# once (the run is killed beyond that), so the rehearsal runs at the largest world size the box allows; nothing in the code paths
-# below depends on the rank count (rank r owns global arenas [r n, (r + 1) n), gathered rows arrive in rank order).
-MAX_GPU_PROCS = 6
+# once -- the test runner itself holds it too, and a first attempt with six ranks was killed by the box's process guard ("7 processes
+# had the GPU open") -- so the rehearsal runs at four ranks; nothing in the code paths below depends on the rank count (rank r owns
+# global arenas [r n, (r + 1) n), gathered rows arrive in rank order).
+MAX_GPU_PROCS = 4
 
 
 @pytest.mark.timeout(900)
 def test_bench_many_ranks_on_one_gpu_prints_a_well_formed_line():
-    """bench.py --gpus 6 --arenas 8192 --steps 20 --warmup 5 under torch.distributed.run, every rank on cuda:0, gloo standing in for
-    RCCL: one line, n_gpus / collectives.ranks = 6, every rank's returns gathered in global arena order."""
+    """bench.py --gpus 4 --arenas 8192 --steps 20 --warmup 5 under torch.distributed.run, every rank on cuda:0, gloo standing in for
+    RCCL: one line, n_gpus / collectives.ranks = 4, every rank's returns gathered in global arena order."""
     world, n = MAX_GPU_PROCS, 8192
     port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
@@ -185,7 +186,7 @@ def test_bench_many_ranks_on_one_gpu_prints_a_well_formed_line():
 
 @pytest.mark.timeout(900)
 def test_many_processes_on_one_gpu_equal_one_batch(tmp_path):
-    """six fresh processes, each with its own arena_offset slice, against ONE process stepping all 6 n arenas: gathered returns and
+    """four fresh processes, each with its own arena_offset slice, against ONE process stepping all 4 n arenas: gathered returns and
     final observations bit for bit (the two-process test above at the largest world size the box admits)."""
     n, steps, world = 1024, 305, MAX_GPU_PROCS
     port = _free_port()

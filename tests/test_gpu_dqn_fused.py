@@ -203,8 +203,8 @@ def test_checkpoint_round_trips_between_fused_and_torch_adam():
         src.learn(); dst.learn()
         torch.cuda.synchronize()
         for (k, p), q in zip(src.Q_eval.named_parameters(), dst.Q_eval.parameters()):
-            d = (p - q).abs()
-            assert float(d.max()) <= 2.5 * src._lr, (src_fused, k, float(d.max()))  # (an entry with a ~0 gradient may step differently)
+            d = (p - q).detach().abs()
+            assert float(d.max()) <= 2.5 * src._lr, (src_fused, k)  # (an entry with a ~0 gradient may step differently)
             assert float(torch.quantile(d.flatten()[:1_000_000], 0.999)) <= 2e-6, (src_fused, k)
         src.close(); dst.close()
         assert src._fused_h is None and dst._fused_h is None
