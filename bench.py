@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--arenas", type=int, default=65536, help="arenas per GPU (weak scaling)")
     ap.add_argument("--preset", default="G", choices=["G", "T", "D"],
                     help="G = constants as checked in (2+2 robots, 4+4 balls, 800x800); T = DQN training preset")
-    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32", "f32_state"])  # f32_state: fp32 records in HBM, fp64 arithmetic (BASELINE config 2)
     ap.add_argument("--policy", default="random", choices=["random", "chase"])
     ap.add_argument("--log-interval", type=int, default=25, help="steps between RCCL all-gathers of episode returns")
     ap.add_argument("--fuse", type=int, default=1, help="steps per launch (rr_rollout, open-loop extension; 1 = one launch per "
@@ -362,7 +362,7 @@ def main():
         line = {
             "metric": "env_steps_per_sec", "value": total_steps / dt, "unit": "env-steps/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64" if args.dtype == "f32_state" else args.dtype, "data": "synthetic",  # the arithmetic type
             "config": {"workload": f"{n} parallel arenas per GPU, SimpleDuel3 preset {args.preset} "
                                    f"({p.nr_happy}+{p.nr_grumpy} robots, {p.nb_pos}+{p.nb_neg} balls, "
                                    f"{int(p.arena_w)}x{int(p.arena_h)}), {args.policy}-policy rollout, {na} action(s)/arena, "
@@ -372,12 +372,14 @@ def main():
                                    + (f", BUDGETED step ({args.budget} clocks): {n_not_ready} NOT_READY rows not counted" if args.budget else "")
                                    + (", EXACT-TRIG parity build (double-double sin / cos)" if args.exact_trig else "")
                                    + (", fp32 FAST MODE: state and arithmetic in fp32 -- the 1e-5 parity bar holds on quiet steps only "
-                                      "(contact steps: statistical, tests/test_gpu_fp32.py); fp64 is the parity mode" if args.dtype == "f32" else ""),
+                                      "(contact steps: statistical, tests/test_gpu_fp32.py); fp64 is the parity mode" if args.dtype == "f32" else "")
+                                   + (", FP32 STATE: the arenas' records in HBM are fp32, a step computes in fp64 between loading a record and "
+                                      "writing it back (single steps within 1e-5 of the fp64 reference, contact steps included)" if args.dtype == "f32_state" else ""),
                        "arenas_per_gpu": n, "preset": args.preset, "policy": args.policy, "lanes_per_arena": env.lanes_per_env(),
                        "sharding": f"dp{world} (independent arena shards, returns all-gathered every "
                                    f"{gather_every} steps and once after the loop)" if world > 1 else "single GPU",
                        "steps_per_launch": F, "fault_status_bits_seen": status_bits, "staggered_phases": bool(stagger),
-                       "fp64_arithmetic": args.dtype == "f64", "exact_trig": bool(args.exact_trig),
+                       "fp64_arithmetic": args.dtype != "f32", "state_dtype": "f64" if args.dtype == "f64" else "f32", "exact_trig": bool(args.exact_trig),
                        "step_budget_clocks": args.budget, "not_ready_fraction": n_not_ready / float(n * K),
                        "collectives": {"all_gather_calls": len(pending), "ranks": world, "backend": rrd.backend_name(),
                                        "bytes_per_rank": 4 * n, "gathered_rows": gathered_rows[-1] if gathered_rows else 0,

@@ -43,6 +43,11 @@ extern "C" {
 
 #define RR_DTYPE_F64 0 /* state + arithmetic in fp64: the parity mode (the reference is fp64)         */
 #define RR_DTYPE_F32 1 /* state + arithmetic in fp32: the fast mode                                   */
+#define RR_DTYPE_F32_STATE 2 /* "fp32 state" (BASELINE config 2): the arenas' records in HBM are fp32, a step computes in fp64 between
+                                loading a record and writing it back -- one rounding per stored value and step, single-step results
+                                within 1e-5 of the fp64 reference on contact steps too.  Default lane widths, rr_step / rr_step_f64 /
+                                rr_step_thrust(_f64) and every side entry; no rr_rollout, no step budget (both would keep unrounded
+                                state across steps) */
 
 #define RR_TEAM_HAPPY 1   /* RR_Constants.py:52 */
 #define RR_TEAM_GRUMPY (-1) /* RR_Constants.py:53 */
@@ -65,7 +70,7 @@ typedef struct rr_config {
     int32_t reset_on_fault; /* 1: a step that ends with a fatal status (the places where the reference raises or
                                spins forever: bits 1|2|4|8|16|32) reports done = 1 and ends the episode, so that
                                auto_reset re-places the arena; 0: the arena keeps stepping with the bit set     */
-    int32_t dtype;          /* RR_DTYPE_F64 | RR_DTYPE_F32                                             */
+    int32_t dtype;          /* RR_DTYPE_F64 | RR_DTYPE_F32 | RR_DTYPE_F32_STATE                        */
     int32_t device;         /* HIP device ordinal                                                      */
     uint64_t seed;          /* keys the counter-based reset RNG                                        */
     uint64_t arena_offset;  /* global id of local arena 0: makes results invariant to sharding         */
@@ -125,7 +130,7 @@ int rr_rollout(rr_env *env, const int32_t *actions, int32_t na, int32_t nsteps, 
  * rounded half-to-even like Python's round() (RR_Robot.py:100-102). */
 int rr_step_thrust(rr_env *env, const float *thrust, int32_t nk, float *obs, float *reward, uint8_t *done,
                    float *obs_g, float *reward_g, int32_t *status, void *stream);
-/* Same entry with fp64 outputs (the thrust entry's observation / reward parity checks; RR_DTYPE_F64 handles only). */
+/* Same entry with fp64 outputs (the thrust entry's observation / reward parity checks; RR_DTYPE_F64 / RR_DTYPE_F32_STATE handles only). */
 int rr_step_thrust_f64(rr_env *env, const float *thrust, int32_t nk, double *obs, double *reward, uint8_t *done,
                        double *obs_g, double *reward_g, int32_t *status, void *stream);
 

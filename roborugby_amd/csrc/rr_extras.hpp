@@ -22,12 +22,12 @@ struct Program { int32_t n; int32_t id[8]; };
 // read-only view of one arena's HBM record (field-major layout of Arena<C>::P)
 template <class C> struct Rec {
     using R = typename C::Real;
-    const R *p;
-    RR_HD R rcx(int r) const { return p[0 * C::NR + r]; }
-    RR_HD R rcy(int r) const { return p[1 * C::NR + r]; }
-    RR_HD R rrot(int r) const { return p[6 * C::NR + r]; }
-    RR_HD R bcx(int b) const { return p[10 * C::NR + 0 * C::NB + b]; }
-    RR_HD R bcy(int b) const { return p[10 * C::NR + 1 * C::NB + b]; }
+    const typename C::Store *p; // (fp32 under the F32State policy: widened on read)
+    RR_HD R rcx(int r) const { return (R)p[0 * C::NR + r]; }
+    RR_HD R rcy(int r) const { return (R)p[1 * C::NR + r]; }
+    RR_HD R rrot(int r) const { return (R)p[6 * C::NR + r]; }
+    RR_HD R bcx(int b) const { return (R)p[10 * C::NR + 0 * C::NB + b]; }
+    RR_HD R bcy(int b) const { return (R)p[10 * C::NR + 1 * C::NB + b]; }
 };
 template <class C> RR_HD void rec_corners(const Rec<C> &q, const SimParams<typename C::Real> &sp, int r, V2<typename C::Real> c[4]) {
     using R = typename C::Real;
@@ -143,7 +143,7 @@ template <class C> RR_HD void goal_state_clear(int32_t *gs) {
 RR_HD int popcount8(int32_t m) { int n = 0; for (int k = 0; k < 16; k++) n += (m >> k) & 1; return n; }
 // rec / irec: the arena's HBM record (mutable: a consumed ball is parked, the episode bookkeeping follows an early end)
 template <class C, typename O>
-RR_HD void goal_step(typename C::Real *rec, int32_t *irec, const SimParams<typename C::Real> &sp, int32_t *gs, bool base_destruction,
+RR_HD void goal_step(typename C::Store *rec, int32_t *irec, const SimParams<typename C::Real> &sp, int32_t *gs, bool base_destruction,
                      O *reward, O *reward_g, uint8_t *done, int32_t *status) {
     using R = typename C::Real;
     constexpr int NR = C::NR, NB = C::NB, BALLS = 10 * NR, ACC = 10 * NR + 8 * NB, I0 = 3 * NR; // irec: step episode ep_len ep_count last_len fault

@@ -73,7 +73,7 @@ __global__ void k_iota(uint32_t *order, int n) {
 
 // env.reset() for masked arenas; also used (init = 1) to build the constructor's state
 template <class C, typename O>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_reset(SimParams<typename C::Real> sp, typename C::Real *recs,
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_reset(SimParams<typename C::Real> sp, typename C::Store *recs,
                                                                int32_t *irecs, int n, const uint8_t *mask, int init,
                                                                O *obs, O *obs_g) {
     using R = typename C::Real;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_reset(SimParams<typena
     const int arena = blockIdx.x * arenas_per_block<C>() + wave;
     if (arena >= n || wave >= arenas_per_block<C>()) return;
     Arena<C> &A = lds[wave];
-    R *rec = recs + (size_t)arena * Arena<C>::P_STRIDE;
+    typename C::Store *rec = recs + (size_t)arena * Arena<C>::P_STRIDE;
     int32_t *irec = irecs + (size_t)arena * Arena<C>::I_STRIDE;
     int st = 0;
     if (init) { // Robot(team, (0,0)) / Ball(color, (0,0)) as built by GameEnv.__init__ (RR_EnvBase.py:85-109)
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_reset(SimParams<typena
 }
 
 template <class C, typename O>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_observe(SimParams<typename C::Real> sp, const typename C::Real *recs,
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_observe(SimParams<typename C::Real> sp, const typename C::Store *recs,
                                                                  const int32_t *irecs, int n, int team, int ridx, int bidx,
                                                                  O *obs) {
     __shared__ Arena<C> lds[arenas_per_block<C>()];
@@ -130,20 +130,20 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_observe(SimParams<type
 
 // canonical fp64 state <-> record (not hot: one thread per arena)
 template <class C>
-__global__ void k_set_state(typename C::Real *recs, int32_t *irecs, int n, const double *robots, const int32_t *ri,
+__global__ void k_set_state(typename C::Store *recs, int32_t *irecs, int n, const double *robots, const int32_t *ri,
                             const double *balls, const int32_t *step) {
     using R = typename C::Real;
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
-    R *rec = recs + (size_t)a * Arena<C>::P_STRIDE;
+    typename C::Store *rec = recs + (size_t)a * Arena<C>::P_STRIDE;
     int32_t *irec = irecs + (size_t)a * Arena<C>::I_STRIDE;
     constexpr int NR = C::NR, NB = C::NB;
     for (int r = 0; r < NR; r++) {
-        for (int f = 0; f < 10; f++) rec[f * NR + r] = (R)robots[((size_t)a * NR + r) * 10 + f];
+        for (int f = 0; f < 10; f++) rec[f * NR + r] = (typename C::Store)robots[((size_t)a * NR + r) * 10 + f];
         for (int f = 0; f < 3; f++) irec[f * NR + r] = ri[((size_t)a * NR + r) * 3 + f];
     }
     for (int b = 0; b < NB; b++)
-        for (int f = 0; f < 8; f++) rec[10 * NR + f * NB + b] = (R)balls[((size_t)a * NB + b) * 8 + f];
+        for (int f = 0; f < 8; f++) rec[10 * NR + f * NB + b] = (typename C::Store)balls[((size_t)a * NB + b) * 8 + f];
     irec[3 * NR + 0] = step[a];
     irec[3 * NR + 5] = 0; // fault flag
     irec[3 * NR + 6] = 0; // no island carried over from the previous step (Arena::I::fzp)
@@ -154,22 +154,22 @@ __global__ void k_set_state(typename C::Real *recs, int32_t *irecs, int n, const
 }
 // centre of the reference's scratch rect (Arena::P::ic, parity build only): xy [N,2]
 template <class C>
-__global__ void k_scratch_rect(typename C::Real *recs, int n, double *xy, int set) {
+__global__ void k_scratch_rect(typename C::Store *recs, int n, double *xy, int set) {
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
 #if RR_CARRY
-    typename C::Real *rec = recs + (size_t)a * Arena<C>::P_STRIDE + 10 * C::NR + 8 * C::NB + 4;
-    for (int k = 0; k < 2; k++) { if (set) rec[k] = (typename C::Real)xy[(size_t)a * 2 + k]; else xy[(size_t)a * 2 + k] = (double)rec[k]; }
+    typename C::Store *rec = recs + (size_t)a * Arena<C>::P_STRIDE + 10 * C::NR + 8 * C::NB + 4;
+    for (int k = 0; k < 2; k++) { if (set) rec[k] = (typename C::Store)xy[(size_t)a * 2 + k]; else xy[(size_t)a * 2 + k] = (double)rec[k]; }
 #else
     (void)recs; (void)xy; (void)set;
 #endif
 }
 template <class C>
-__global__ void k_get_state(const typename C::Real *recs, const int32_t *irecs, int n, double *robots, int32_t *ri,
+__global__ void k_get_state(const typename C::Store *recs, const int32_t *irecs, int n, double *robots, int32_t *ri,
                             double *balls, int32_t *step) {
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
-    const typename C::Real *rec = recs + (size_t)a * Arena<C>::P_STRIDE;
+    const typename C::Store *rec = recs + (size_t)a * Arena<C>::P_STRIDE;
     const int32_t *irec = irecs + (size_t)a * Arena<C>::I_STRIDE;
     constexpr int NR = C::NR, NB = C::NB;
     for (int r = 0; r < NR; r++) {
@@ -183,7 +183,7 @@ __global__ void k_get_state(const typename C::Real *recs, const int32_t *irecs, 
 // rr_set_poses, and env.reset(bln_randomize_pos=False) = _set_starting_positions (RR_EnvBase.py:131-153,202-216) through
 // rr_reset_to_poses: masked arenas only, first observations out
 template <class C, typename O>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_set_poses(SimParams<typename C::Real> sp, typename C::Real *recs,
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_set_poses(SimParams<typename C::Real> sp, typename C::Store *recs,
                                                                    int32_t *irecs, int n, const double *rxyr,
                                                                    const double *bxyv, const uint8_t *mask, O *obs, O *obs_g) {
     using R = typename C::Real;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_set_poses(SimParams<ty
     if (arena >= n || wave >= arenas_per_block<C>()) return;
     if (mask && !mask[arena]) return; // uniform per virtual wave
     Arena<C> &A = lds[wave];
-    R *rec = recs + (size_t)arena * Arena<C>::P_STRIDE;
+    typename C::Store *rec = recs + (size_t)arena * Arena<C>::P_STRIDE;
     int32_t *irec = irecs + (size_t)arena * Arena<C>::I_STRIDE;
     load_record(A, rec, irec);
     if (lane < C::NR) {
@@ -217,21 +217,21 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_set_poses(SimParams<ty
 }
 // episode bookkeeping <-> caller (checkpoint / resume): ints [N,5] = episode, ep_len, ep_count, last_len, fault; acc [N,4]
 template <class C>
-__global__ void k_episode_state(typename C::Real *recs, int32_t *irecs, int n, int32_t *ints, double *acc, int set) {
+__global__ void k_episode_state(typename C::Store *recs, int32_t *irecs, int n, int32_t *ints, double *acc, int set) {
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
-    typename C::Real *rec = recs + (size_t)a * Arena<C>::P_STRIDE;
+    typename C::Store *rec = recs + (size_t)a * Arena<C>::P_STRIDE;
     int32_t *irec = irecs + (size_t)a * Arena<C>::I_STRIDE;
     constexpr int ACC = 10 * C::NR + 8 * C::NB, I0 = 3 * C::NR + 1; // after mc/thl/thr and step
     for (int k = 0; k < 5; k++) { if (set) irec[I0 + k] = ints[(size_t)a * 5 + k]; else ints[(size_t)a * 5 + k] = irec[I0 + k]; }
-    for (int k = 0; k < 4; k++) { if (set) rec[ACC + k] = (typename C::Real)acc[(size_t)a * 4 + k]; else acc[(size_t)a * 4 + k] = (double)rec[ACC + k]; }
+    for (int k = 0; k < 4; k++) { if (set) rec[ACC + k] = (typename C::Store)acc[(size_t)a * 4 + k]; else acc[(size_t)a * 4 + k] = (double)rec[ACC + k]; }
 }
 template <class C>
-__global__ void k_episode_stats(const typename C::Real *recs, const int32_t *irecs, int n, float *lr, float *lrg,
+__global__ void k_episode_stats(const typename C::Store *recs, const int32_t *irecs, int n, float *lr, float *lrg,
                                 int32_t *ll, int32_t *cnt) {
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
-    const typename C::Real *rec = recs + (size_t)a * Arena<C>::P_STRIDE;
+    const typename C::Store *rec = recs + (size_t)a * Arena<C>::P_STRIDE;
     const int32_t *irec = irecs + (size_t)a * Arena<C>::I_STRIDE;
     constexpr int ACC = 10 * C::NR + 8 * C::NB;
     if (lr) lr[a] = (float)rec[ACC + 2];
@@ -242,7 +242,7 @@ __global__ void k_episode_stats(const typename C::Real *recs, const int32_t *ire
 
 // ---- other mixins (rr_extras.hpp): thread-per-arena side kernels, straight from the HBM records
 template <class C>
-__global__ void k_extras_begin(const typename C::Real *recs, int n, typename C::Real *xs, const uint8_t *mask = nullptr) {
+__global__ void k_extras_begin(const typename C::Store *recs, int n, typename C::Real *xs, const uint8_t *mask = nullptr) {
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n || (mask && !mask[a])) return;
     Rec<C> q = { recs + (size_t)a * Arena<C>::P_STRIDE };
@@ -252,13 +252,13 @@ __global__ void k_extras_begin(const typename C::Real *recs, int n, typename C::
 // fused SimpleDuel3 ones AND feed the episode-return accumulators (k_step leaves them alone then: sp.acc_external), and an
 // arena that k_step re-placed (auto-reset) gets its on_step_begin copies re-seeded from the new poses, like rr_reset does.
 template <class C, typename O>
-__global__ void k_extras_end(SimParams<typename C::Real> sp, typename C::Real *recs, int n, typename C::Real *xs,
+__global__ void k_extras_end(SimParams<typename C::Real> sp, typename C::Store *recs, int n, typename C::Real *xs,
                              Program pg, int rewrite, O *reward, O *reward_g, int32_t *status, const uint8_t *done) {
     using R = typename C::Real;
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
     const int32_t st = status[a];
-    R *rec = recs + (size_t)a * Arena<C>::P_STRIDE;
+    typename C::Store *rec = recs + (size_t)a * Arena<C>::P_STRIDE;
     Rec<C> q = { rec };
     if (st & ST_WAS_RESET) { extras_begin<C>(q, xs + (size_t)a * xs_stride<C>()); return; } // new episode: no prior step yet
     if (!rewrite || (st & ST_STEP_AFTER_DONE)) return; // nothing was stepped: the reward stays 0
@@ -271,7 +271,7 @@ __global__ void k_extras_end(SimParams<typename C::Real> sp, typename C::Real *r
 }
 // opt-in goal scoring (rr_extras.hpp: goal_step): thread per arena, after k_step (and k_extras_end)
 template <class C, typename O>
-__global__ void k_goal(SimParams<typename C::Real> sp, typename C::Real *recs, int32_t *irecs, int n, int32_t *gs, int base_destruction,
+__global__ void k_goal(SimParams<typename C::Real> sp, typename C::Store *recs, int32_t *irecs, int n, int32_t *gs, int base_destruction,
                        O *reward, O *reward_g, uint8_t *done, int32_t *status) {
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
@@ -292,7 +292,7 @@ __global__ void k_goal_scores(int n, const int32_t *gs, int32_t *scores) { // Go
     for (int k = 0; k < 2; k++) scores[2 * a + k] = 500 * (popcount8(g[k]) - popcount8(g[2 + k]));
 }
 template <class C, typename O>
-__global__ void k_observe_kind(SimParams<typename C::Real> sp, const typename C::Real *recs, int n, int kind, int team, int ridx,
+__global__ void k_observe_kind(SimParams<typename C::Real> sp, const typename C::Store *recs, int n, int kind, int team, int ridx,
                                int bidx, O *obs, int dim, const typename C::Real *xs) {
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void k_copy16(const u32x4 *__restrict__ src, u
 // ------------------------------------------------------------------------------------------------ host side
 struct rr_env {
     rr_config cfg;
-    int kind; // shape + RR_NUM_SHAPES * (dtype == f32): 0 T64, 1 G64, 2 D64, 3 T32, 4 G32, 5 D32
+    int kind; // shape + RR_NUM_SHAPES * dtype: 0 T64, 1 G64, 2 D64, 3 T32, 4 G32, 5 D32, 6-8 T / G / D with fp32 state and fp64 arithmetic
     int vw;   // lanes per arena
     void *recs;
     int32_t *irecs;      // the int part of the records: recs + P_REALS (same allocation, same stride)
@@ -426,7 +426,8 @@ int rr_create(const rr_config *cfg, rr_env **out) {
     else if (cfg->nr_happy == 2 && cfg->nr_grumpy == 2 && cfg->nb_pos == 4 && cfg->nb_neg == 4) shape = 1;
     else if (cfg->nr_happy == 1 && cfg->nr_grumpy == 1 && cfg->nb_pos == 1 && cfg->nb_neg == 1) shape = 2;
     else return fail(-1, "rr_create: unsupported entity counts (built shapes: 1+0 robots/1+0 balls, 2+2 robots/4+4 balls, 1+1 robots/1+1 balls)");
-    if (cfg->dtype != RR_DTYPE_F64 && cfg->dtype != RR_DTYPE_F32) return fail(-1, "rr_create: bad dtype");
+    if (cfg->dtype != RR_DTYPE_F64 && cfg->dtype != RR_DTYPE_F32 && cfg->dtype != RR_DTYPE_F32_STATE) return fail(-1, "rr_create: bad dtype");
+    if (cfg->dtype == RR_DTYPE_F32_STATE && cfg->step_budget_clocks) return fail(-1, "rr_create: no step budget with RR_DTYPE_F32_STATE");
     if (!(cfg->arena_w >= 300 && cfg->arena_h >= 300 && cfg->arena_w <= 8192 && cfg->arena_h <= 8192))
         return fail(-1, "rr_create: arena size out of range [300, 8192]");
     if (cfg->game_len_steps <= 0) return fail(-1, "rr_create: game_len_steps must be positive");
@@ -437,7 +438,7 @@ int rr_create(const rr_config *cfg, rr_env **out) {
     rr_env *e = new (std::nothrow) rr_env();
     if (!e) return fail(-3, "rr_create: out of host memory");
     e->cfg = *cfg;
-    e->kind = shape + RR_NUM_SHAPES * (cfg->dtype == RR_DTYPE_F32 ? 1 : 0);
+    e->kind = shape + RR_NUM_SHAPES * cfg->dtype;
     e->vw = 0;
     e->prog.n = 3; e->prog.id[0] = KEEPER_NAUGHTY; e->prog.id[1] = KEEPER_CHASE; e->prog.id[2] = KEEPER_PUSHPOS;
     e->custom_prog = false; e->track_prior = false; e->xs = nullptr; e->status_buf = nullptr; e->gs = nullptr;
@@ -451,7 +452,7 @@ int rr_create(const rr_config *cfg, rr_env **out) {
     fill_params(e->spd, *cfg);
     fill_params(e->spf, *cfg);
     size_t pstride = 0, preals = 0, snapw = 0, isnapw = 0;
-    const size_t rsz = cfg->dtype == RR_DTYPE_F32 ? 4 : 8;
+    const size_t rsz = cfg->dtype == RR_DTYPE_F64 ? 8 : 4; // bytes per STORED real (the record)
     dispatch(e, [&](auto c) {
         using CC = decltype(c);
         pstride = Arena<CC>::P_STRIDE; preals = Arena<CC>::P_REALS; snapw = Arena<CC>::SNAP_WORDS; isnapw = Arena<CC>::ISNAP_WORDS;
@@ -495,7 +496,7 @@ int rr_create(const rr_config *cfg, rr_env **out) {
     // constructor placement (RR_EnvBase.py:111-116): episode 0 of the counter RNG
     dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
-        hipLaunchKernelGGL((k_reset<CC, float>), arena_grid<CC>(n), wave_block(), 0, 0, params_of<RR>(e), (RR *)e->recs,
+        hipLaunchKernelGGL((k_reset<CC, float>), arena_grid<CC>(n), wave_block(), 0, 0, params_of<RR>(e), (typename CC::Store *)e->recs,
                            e->irecs, n, (const uint8_t *)nullptr, 1, (float *)nullptr, (float *)nullptr);
         return 0;
     });
@@ -540,9 +541,9 @@ int rr_reset(rr_env *e, const uint8_t *mask, float *obs, float *obs_g, void *str
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
         hipLaunchKernelGGL((k_reset<CC, float>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
-                           (RR *)e->recs, e->irecs, n, mask, 0, obs, obs_g);
+                           (typename CC::Store *)e->recs, e->irecs, n, mask, 0, obs, obs_g);
         if (e->track_prior && e->xs) // a re-placed arena has no prior step yet: its copies restart from the new poses
-            hipLaunchKernelGGL((k_extras_begin<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const RR *)e->recs, n, (RR *)e->xs, mask);
+            hipLaunchKernelGGL((k_extras_begin<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const typename CC::Store *)e->recs, n, (RR *)e->xs, mask);
         if (e->gs) hipLaunchKernelGGL((k_goal_clear<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, n, e->gs, mask); // Goal.on_reset
         return 0;
     });
@@ -578,17 +579,23 @@ static int step_impl(rr_env *e, const int32_t *actions, const float *thrust, int
             return fail(-1, "fp64 outputs need a handle created with RR_DTYPE_F64");
         } else {
             if (e->custom_prog || e->track_prior)
-                hipLaunchKernelGGL((k_extras_begin<CC>), dim3((n + 127) / 128), dim3(128), 0, s, (const RR *)e->recs, n, (RR *)e->xs, (const uint8_t *)nullptr);
+                hipLaunchKernelGGL((k_extras_begin<CC>), dim3((n + 127) / 128), dim3(128), 0, s, (const typename CC::Store *)e->recs, n, (RR *)e->xs, (const uint8_t *)nullptr);
+            if constexpr (CC::MIXED) { // fp32 state: the plain single-step kernel only (rr_set_step_budget / rr_rollout refuse the handle)
+                if (nsteps != 1 || e->park) return fail(-1, "RR_DTYPE_F32_STATE: rr_step only (no rr_rollout, no step budget)");
+                hipLaunchKernelGGL((k_step<CC, O, false>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (typename CC::Store *)e->recs, e->irecs, n,
+                                   actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status, (const uint32_t *)e->order, e->cost,
+                                   1, 0, e->snap, e->isnap);
+            } else
             if (nsteps == 1 && e->park)
-                hipLaunchKernelGGL((k_step<CC, O, false, true>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (RR *)e->recs, e->irecs, n,
+                hipLaunchKernelGGL((k_step<CC, O, false, true>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (typename CC::Store *)e->recs, e->irecs, n,
                                    actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status, (const uint32_t *)e->order, e->cost,
                                    1, 0, e->snap, e->isnap, e->park, e->budget);
             else if (nsteps == 1)
-                hipLaunchKernelGGL((k_step<CC, O, false>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (RR *)e->recs, e->irecs, n,
+                hipLaunchKernelGGL((k_step<CC, O, false>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (typename CC::Store *)e->recs, e->irecs, n,
                                    actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status, (const uint32_t *)e->order, e->cost,
                                    1, 0, e->snap, e->isnap);
             else if constexpr (std::is_same<O, float>::value && CC::VW == default_vw<CC>()) // default lane widths only (build time)
-                hipLaunchKernelGGL((k_step<CC, O, true>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (RR *)e->recs, e->irecs, n,
+                hipLaunchKernelGGL((k_step<CC, O, true>), arena_grid<CC>(n), wave_block(), 0, s, params_of<RR>(e), (typename CC::Store *)e->recs, e->irecs, n,
                                    actions, thrust, (int)na, obs, reward, done, obs_g, reward_g, status, (const uint32_t *)e->order, e->cost,
                                    nsteps, repeat, e->snap, e->isnap);
             else
@@ -596,12 +603,12 @@ static int step_impl(rr_env *e, const int32_t *actions, const float *thrust, int
             if (e->order) hipLaunchKernelGGL(k_order, dim3(1), dim3(ORDER_THREADS), 0, s, (const uint32_t *)e->cost, e->order, e->ngroups);
             if (e->custom_prog || e->track_prior)
                 hipLaunchKernelGGL((k_extras_end<CC, O>), dim3((n + 127) / 128), dim3(128), 0, s, params_of<RR>(e),
-                                   (RR *)e->recs, n, (RR *)e->xs, e->prog, e->custom_prog ? 1 : 0, reward, reward_g, status,
+                                   (typename CC::Store *)e->recs, n, (RR *)e->xs, e->prog, e->custom_prog ? 1 : 0, reward, reward_g, status,
                                    (const uint8_t *)done);
             if (e->gs) {
                 int bd = 0;
                 for (int k = 0; k < e->prog.n; k++) bd |= e->prog.id[k] == KEEPER_BASEDESTRUCTION;
-                hipLaunchKernelGGL((k_goal<CC, O>), dim3((n + 127) / 128), dim3(128), 0, s, params_of<RR>(e), (RR *)e->recs, e->irecs, n,
+                hipLaunchKernelGGL((k_goal<CC, O>), dim3((n + 127) / 128), dim3(128), 0, s, params_of<RR>(e), (typename CC::Store *)e->recs, e->irecs, n,
                                    e->gs, bd, reward, reward_g, done, status);
             }
             return 0;
@@ -645,7 +652,7 @@ int rr_step_thrust_f64(rr_env *e, const float *thrust, int32_t nk, double *obs, 
 
 static int ensure_snapshot_buffer(rr_env *e) { // on_step_begin snapshot of every arena (xs_stride reals each)
     if (e->xs) return 0;
-    const size_t rsz = e->cfg.dtype == RR_DTYPE_F32 ? 4 : 8;
+    const size_t rsz = e->cfg.dtype == RR_DTYPE_F32 ? 4 : 8; // (arithmetic reals)
     const size_t nr = (size_t)(e->cfg.nr_happy + e->cfg.nr_grumpy), nb = (size_t)(e->cfg.nb_pos + e->cfg.nb_neg);
     HIP_TRY(hipMalloc(&e->xs, rsz * (3 * nr + 1 + 2 * nb) * (size_t)e->cfg.num_envs));
     return 0;
@@ -674,6 +681,8 @@ int rr_set_reward_program(rr_env *e, const int32_t *ids, int32_t n) {
 
 int rr_set_step_budget(rr_env *e, uint32_t clocks) {
     if (!e) return fail(-1, "rr_set_step_budget: null handle");
+    if (clocks && e->cfg.dtype == RR_DTYPE_F32_STATE) // (a parked arena's record would be rounded to fp32 in the middle of its step)
+        return fail(-1, "rr_set_step_budget: not with RR_DTYPE_F32_STATE");
     if (clocks && (e->custom_prog || e->track_prior || e->gs))
         return fail(-1, "rr_set_step_budget: SimpleDuel3's own reward stack only (no custom reward program / prior-step tracking / goal scoring)");
     DeviceGuard guard(e->cfg.device);
@@ -740,7 +749,7 @@ int rr_track_prior_step(rr_env *e, int32_t on, void *stream) {
     const int n = e->cfg.num_envs;
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
-        hipLaunchKernelGGL((k_extras_begin<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const RR *)e->recs, n, (RR *)e->xs, (const uint8_t *)nullptr);
+        hipLaunchKernelGGL((k_extras_begin<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const typename CC::Store *)e->recs, n, (RR *)e->xs, (const uint8_t *)nullptr);
         return 0;
     });
     if (rc) return rc;
@@ -769,10 +778,10 @@ static int observe_kind_impl(rr_env *e, int32_t kind, int32_t team, int32_t ridx
         } else {
             if (kind == OBS_V2)
                 hipLaunchKernelGGL((k_observe<CC, O>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
-                                   (const RR *)e->recs, (const int32_t *)e->irecs, n, (int)team, (int)ridx, (int)bidx, obs);
+                                   (const typename CC::Store *)e->recs, (const int32_t *)e->irecs, n, (int)team, (int)ridx, (int)bidx, obs);
             else
                 hipLaunchKernelGGL((k_observe_kind<CC, O>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, params_of<RR>(e),
-                                   (const RR *)e->recs, n, (int)kind, (int)team, (int)ridx, (int)bidx, obs, (int)out_dim,
+                                   (const typename CC::Store *)e->recs, n, (int)kind, (int)team, (int)ridx, (int)bidx, obs, (int)out_dim,
                                    kind == OBS_ALLCOORDS_PRIOR ? (const RR *)e->xs : (const RR *)nullptr);
             return 0;
         }
@@ -802,7 +811,7 @@ int rr_observe(rr_env *e, int32_t team, int32_t ridx, int32_t bidx, float *obs, 
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
         hipLaunchKernelGGL((k_observe<CC, float>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
-                           (const RR *)e->recs, (const int32_t *)e->irecs, n, (int)team, (int)ridx, (int)bidx, obs);
+                           (const typename CC::Store *)e->recs, (const int32_t *)e->irecs, n, (int)team, (int)ridx, (int)bidx, obs);
         return 0;
     });
     if (rc) return rc;
@@ -817,7 +826,7 @@ int rr_observe_f64(rr_env *e, int32_t team, int32_t ridx, int32_t bidx, double *
         using CC = decltype(c); using RR = typename CC::Real;
         if constexpr (std::is_same<RR, double>::value) {
             hipLaunchKernelGGL((k_observe<CC, double>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream,
-                               params_of<RR>(e), (const RR *)e->recs, (const int32_t *)e->irecs, n, (int)team, (int)ridx,
+                               params_of<RR>(e), (const typename CC::Store *)e->recs, (const int32_t *)e->irecs, n, (int)team, (int)ridx,
                                (int)bidx, obs);
             return 0;
         } else {
@@ -835,7 +844,7 @@ int rr_set_state(rr_env *e, const double *robots, const int32_t *ri, const doubl
     DeviceGuard guard(e->cfg.device);
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
-        hipLaunchKernelGGL((k_set_state<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (RR *)e->recs, e->irecs,
+        hipLaunchKernelGGL((k_set_state<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (typename CC::Store *)e->recs, e->irecs,
                            n, robots, ri, balls, step);
         return 0;
     });
@@ -849,7 +858,7 @@ int rr_get_state(rr_env *e, double *robots, int32_t *ri, double *balls, int32_t 
     DeviceGuard guard(e->cfg.device);
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
-        hipLaunchKernelGGL((k_get_state<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const RR *)e->recs,
+        hipLaunchKernelGGL((k_get_state<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const typename CC::Store *)e->recs,
                            (const int32_t *)e->irecs, n, robots, ri, balls, step);
         return 0;
     });
@@ -863,9 +872,9 @@ static int set_poses_impl(rr_env *e, const uint8_t *mask, const double *rxyr, co
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
         hipLaunchKernelGGL((k_set_poses<CC, float>), arena_grid<CC>(n), wave_block(), 0, (hipStream_t)stream, params_of<RR>(e),
-                           (RR *)e->recs, e->irecs, n, rxyr, bxyv, mask, obs, obs_g);
+                           (typename CC::Store *)e->recs, e->irecs, n, rxyr, bxyv, mask, obs, obs_g);
         if (e->track_prior && e->xs) // like rr_reset: a re-placed arena has no prior step yet
-            hipLaunchKernelGGL((k_extras_begin<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const RR *)e->recs, n, (RR *)e->xs, mask);
+            hipLaunchKernelGGL((k_extras_begin<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const typename CC::Store *)e->recs, n, (RR *)e->xs, mask);
         if (e->gs) hipLaunchKernelGGL((k_goal_clear<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, n, e->gs, mask);
         return 0;
     });
@@ -887,7 +896,7 @@ static int episode_state_impl(rr_env *e, int32_t *ints, double *acc, int set, vo
     DeviceGuard guard(e->cfg.device);
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
-        hipLaunchKernelGGL((k_episode_state<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (RR *)e->recs, e->irecs, n, ints, acc, set);
+        hipLaunchKernelGGL((k_episode_state<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (typename CC::Store *)e->recs, e->irecs, n, ints, acc, set);
         return 0;
     });
     if (rc) return rc;
@@ -901,7 +910,7 @@ static int scratch_rect_impl(rr_env *e, double *xy, int set, void *stream) {
     DeviceGuard guard(e->cfg.device);
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
-        hipLaunchKernelGGL((k_scratch_rect<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (RR *)e->recs, n, xy, set);
+        hipLaunchKernelGGL((k_scratch_rect<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (typename CC::Store *)e->recs, n, xy, set);
         return 0;
     });
     if (rc) return rc;
@@ -920,7 +929,7 @@ int rr_episode_stats(rr_env *e, float *lr, float *lrg, int32_t *ll, int32_t *cnt
     DeviceGuard guard(e->cfg.device);
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
-        hipLaunchKernelGGL((k_episode_stats<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const RR *)e->recs,
+        hipLaunchKernelGGL((k_episode_stats<CC>), dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const typename CC::Store *)e->recs,
                            (const int32_t *)e->irecs, n, lr, lrg, ll, cnt);
         return 0;
     });

@@ -14,25 +14,26 @@
 using namespace rr;
 
 // ------------------------------------------------------------------------------------------------ device side
-template <class C> __device__ __forceinline__ void load_record(Arena<C> &A, const typename C::Real *rec, const int32_t *irec) {
+// (under the F32State policy `rec` holds fp32 values: they are widened on the way into LDS and rounded once on the way back)
+template <class C> __device__ __forceinline__ void load_record(Arena<C> &A, const typename C::Store *rec, const int32_t *irec) {
     using R = typename C::Real;
     R *p = reinterpret_cast<R *>(&A.p);
     int32_t *q = reinterpret_cast<int32_t *>(&A.i);
     const int lane = threadIdx.x & (C::VW - 1);
-    for (int k = lane; k < Arena<C>::P_REALS; k += C::VW) p[k] = rec[k];
+    for (int k = lane; k < Arena<C>::P_REALS; k += C::VW) p[k] = (R)rec[k];
     for (int k = lane; k < Arena<C>::I_INTS; k += C::VW) q[k] = irec[k];
     RR_SYNC();
 }
-template <class C> __device__ __forceinline__ void store_record(const Arena<C> &A, typename C::Real *rec, int32_t *irec) {
+template <class C> __device__ __forceinline__ void store_record(const Arena<C> &A, typename C::Store *rec, int32_t *irec) {
     using R = typename C::Real;
     const R *p = reinterpret_cast<const R *>(&A.p);
     const int32_t *q = reinterpret_cast<const int32_t *>(&A.i);
     const int lane = threadIdx.x & (C::VW - 1);
     RR_SYNC();
-    for (int k = lane; k < Arena<C>::P_REALS; k += C::VW) rec[k] = p[k];
+    for (int k = lane; k < Arena<C>::P_REALS; k += C::VW) rec[k] = (typename C::Store)p[k];
     // the ints and the record's padding: the whole 64-B tail is written, so no line of the record is left partially
     // dirty (a partial line costs a read-for-merge in L2: 0.3 KB per env-step showed up in FETCH_SIZE)
-    constexpr int TAIL = Arena<C>::I_STRIDE - Arena<C>::P_REALS * Arena<C>::WR;
+    constexpr int TAIL = Arena<C>::I_STRIDE - Arena<C>::P_REALS * Arena<C>::WS;
     for (int k = lane; k < TAIL; k += C::VW) irec[k] = k < Arena<C>::I_INTS ? q[k] : 0;
 }
 
@@ -65,7 +66,7 @@ template <class C> constexpr int lds_waves_per_simd() {
 // instantiations: the loop around step_arena costs the single-step kernel 12 % (measured) through register allocation alone.
 // BUDGET = true: the budgeted step (rr_sim.hpp: ParkCtx) -- a separate instantiation, so the default kernel carries none of it.
 template <class C, typename O, bool MULTI, bool BUDGET = false>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void k_step(SimParams<typename C::Real> sp, typename C::Real *recs,
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void k_step(SimParams<typename C::Real> sp, typename C::Store *recs,
                                                               int32_t *irecs, int n, const int32_t *actions,
                                                               const float *thrust, int na, O *obs, O *reward,
                                                               uint8_t *done, O *obs_g, O *reward_g, int32_t *status,
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
     const int arena = group * arenas_per_block<C>() + wave;
     if (arena >= n) return; // uniform per virtual wave; no workgroup barrier is ever used
     Arena<C> &A = lds[wave];
-    typename C::Real *rec = recs + (size_t)arena * Arena<C>::P_STRIDE;
+    typename C::Store *rec = recs + (size_t)arena * Arena<C>::P_STRIDE;
     int32_t *irec = irecs + (size_t)arena * Arena<C>::I_STRIDE;
     RR_T0();
 #if defined(RR_PROFILE_PHASES)
@@ -143,7 +144,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
 #endif
 }
 
-// Built configurations: (kind = shape + 3*dtype, entity counts, Real, VW); shapes: 0 = T (1+0 robots, 1+0 balls), 1 = G (2+2, 4+4),
+// Built configurations: (kind = shape + 3*dtype, entity counts, precision policy, VW) -- dtype 0: fp64, 1: fp32, 2: fp32 state with fp64
+// arithmetic (rr_sim.hpp: F32State; default lane widths only, no budgeted / multi-step variant); shapes: 0 = T (1+0 robots, 1+0 balls), 1 = G (2+2, 4+4),
 // 2 = D (1+1 robots, 1+1 balls: the two-team duel).  The first VW listed for a kind is the default; the environment variable
 // RR_VW selects another built width (kernel tuning / A-B runs).
 #if defined(RR_CFG_SUBSET) && RR_CFG_SUBSET == 2 // occupancy probe: T at 4 lanes per arena (its LDS admits 4 waves per SIMD)
@@ -159,7 +161,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
     X(2, 1, 1, 1, 1, double, 4) X(2, 1, 1, 1, 1, double, 8) X(2, 1, 1, 1, 1, double, 64)                              \
     X(3, 1, 0, 1, 0, float, 2) X(3, 1, 0, 1, 0, float, 4) X(3, 1, 0, 1, 0, float, 64)                                 \
     X(4, 2, 2, 4, 4, float, 8) X(4, 2, 2, 4, 4, float, 16) X(4, 2, 2, 4, 4, float, 64)                                \
-    X(5, 1, 1, 1, 1, float, 4)
+    X(5, 1, 1, 1, 1, float, 4)                                                                                        \
+    X(6, 1, 0, 1, 0, F32State, 2) X(7, 2, 2, 4, 4, F32State, 8) X(8, 1, 1, 1, 1, F32State, 4)
 #endif
 constexpr int RR_NUM_SHAPES = 3;
 // default lanes per arena of a shape (the widths rr_rollout's multi-step variant is built for)
@@ -177,9 +180,13 @@ template <class C> constexpr int default_vw() { return C::NR == 1 ? 2 : C::NR ==
     X(6, 1, 0, 1, 0, float, 2, 1) X(6, 1, 0, 1, 0, float, 4, 0) X(6, 1, 0, 1, 0, float, 64, 0)                         \
     X(4, 2, 2, 4, 4, float, 8, 1) X(4, 2, 2, 4, 4, float, 16, 0) X(5, 2, 2, 4, 4, float, 64, 0)                        \
     X(0, 1, 1, 1, 1, float, 4, 1)
+// fp32 state / fp64 arithmetic: the plain single-step kernel only, float and double outputs
+#define RR_FOR_EACH_CFG_F32S_PARTS(X) X(5, 1, 0, 1, 0, F32State, 2, 0) X(2, 2, 2, 4, 4, F32State, 8, 0) X(6, 1, 1, 1, 1, F32State, 4, 0)
+#define RR_KSTEP_PLAIN(PREFIX, a, b, c, d, R_, vw_, O_) \
+    PREFIX template __global__ void k_step<Cfg<a, b, c, d, R_, vw_>, O_, false, false> RR_KSTEP_SIG(RR_KSTEP_CFG(a, b, c, d, R_, vw_), O_);
 
 #define RR_KSTEP_SIG(C_, O_)                                                                                                       \
-    (SimParams<typename C_::Real>, typename C_::Real *, int32_t *, int, const int32_t *, const float *, int, O_ *, O_ *, uint8_t *, \
+    (SimParams<typename C_::Real>, typename C_::Store *, int32_t *, int, const int32_t *, const float *, int, O_ *, O_ *, uint8_t *, \
      O_ *, O_ *, int32_t *, const uint32_t *, uint32_t *, int, int, uint32_t *, int32_t *, uint32_t *, uint32_t)
 // every variant step_impl can launch for one configuration and one output type: plain, budgeted, and (default widths, float
 // outputs) rr_rollout's multi-step loop
@@ -199,5 +206,8 @@ RR_FOR_EACH_CFG_F64_PARTS(X)
 #undef X
 #define X(part, a, b, c, d, R_, vw_, def_) RR_KSTEP_VARIANTS(extern, a, b, c, d, R_, vw_, float, def_)
 RR_FOR_EACH_CFG_F32_PARTS(X)
+#undef X
+#define X(part, a, b, c, d, R_, vw_, def_) RR_KSTEP_PLAIN(extern, a, b, c, d, R_, vw_, float) RR_KSTEP_PLAIN(extern, a, b, c, d, R_, vw_, double)
+RR_FOR_EACH_CFG_F32S_PARTS(X)
 #undef X
 #endif

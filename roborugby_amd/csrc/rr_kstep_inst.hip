@@ -48,3 +48,6 @@ RR_FOR_EACH_CFG_F64_PARTS(X)
 #define X(part, a, b, c, d, R_, vw_, def_) RR_IF_PART_##part(RR_KSTEP_VARIANTS(RR_NOTHING, a, b, c, d, R_, vw_, float, def_))
 RR_FOR_EACH_CFG_F32_PARTS(X)
 #undef X
+#define X(part, a, b, c, d, R_, vw_, def_) RR_IF_PART_##part(RR_KSTEP_PLAIN(RR_NOTHING, a, b, c, d, R_, vw_, float) RR_KSTEP_PLAIN(RR_NOTHING, a, b, c, d, R_, vw_, double))
+RR_FOR_EACH_CFG_F32S_PARTS(X)
+#undef X

@@ -388,13 +388,22 @@ template <typename R> RR_HD R angle_degrees(V2<R> a, V2<R> b, int &st) {
 }
 
 // ------------------------------------------------------------------------------------------------ config
-template <int NRH_, int NRG_, int NBP_, int NBN_, typename Real_, int VW_ = 64> struct Cfg {
+// Precision policy of a configuration: `double` / `float` = state and arithmetic in that type; F32State = the arena's record in HBM is
+// fp32 ("fp32 state", BASELINE config 2) while a step computes in fp64 from the moment the record is loaded into LDS to the moment it
+// is written back -- one rounding per stored value and step, which is what keeps a contact step within 1e-5 of the fp64 reference
+// (the all-fp32 mode's cancellations in the contact responses do not: DESIGN.md section 3).
+struct F32State {};
+template <typename T> struct Precision { using Real = T; using Store = T; };
+template <> struct Precision<F32State> { using Real = double; using Store = float; };
+template <int NRH_, int NRG_, int NBP_, int NBN_, typename Prec_, int VW_ = 64> struct Cfg {
     static constexpr int NRH = NRH_, NRG = NRG_, NBP = NBP_, NBN = NBN_;
     static constexpr int NR = NRH_ + NRG_, NB = NBP_ + NBN_;
     static constexpr int NPR = NR * (NR - 1) / 2; // robot pairs
     static constexpr int NPB = NB * (NB - 1) / 2; // ball pairs
     static constexpr int VW = VW_;                // lanes per arena (virtual wave width)
-    using Real = Real_;
+    using Real = typename Precision<Prec_>::Real;   // arithmetic, and the arena's LDS image
+    using Store = typename Precision<Prec_>::Store; // the persistent record in HBM
+    static constexpr bool MIXED = sizeof(Store) != sizeof(Real);
     static_assert(VW == 2 || VW == 4 || VW == 8 || VW == 16 || VW == 32 || VW == 64, "VW must divide the wavefront");
     static_assert(NR >= 1 && NR <= VW && NB >= 1 && NB <= VW, "one lane per entity");
     static_assert(NB * NR <= 32 && NPB <= 64 && NB <= 16 && NR <= 16, "pair masks are 32/64-bit, per-ball masks 16-bit");
@@ -468,10 +477,12 @@ template <class C> struct ArenaBody {
     static constexpr int I_INTS = (int)(sizeof(I) / sizeof(int32_t));
     // HBM record of one arena: the P reals, the I ints right behind them, padded to a 64-B multiple (so that the lane-strided
     // runs of the arenas sharing a wavefront start on request boundaries).  G/fp64: 108 reals + 20 ints = 944 -> 960 B.
+    // (the record holds `Store` values -- fp32 under the F32State policy --, everything else here is in arithmetic reals)
     static constexpr int WR = (int)(sizeof(R) / 4);                       // 32-bit words per real
-    static constexpr int P_ALIGN = 64 / (int)sizeof(R);
-    static constexpr int P_STRIDE = (P_REALS + (I_INTS + WR - 1) / WR + P_ALIGN - 1) / P_ALIGN * P_ALIGN; // reals per record
-    static constexpr int I_STRIDE = P_STRIDE * WR;                         // the same stride seen from the int part (irecs = recs + P_REALS)
+    static constexpr int WS = (int)(sizeof(typename C::Store) / 4);       // 32-bit words per stored real
+    static constexpr int P_ALIGN = 64 / (int)sizeof(typename C::Store);
+    static constexpr int P_STRIDE = (P_REALS + (I_INTS + WS - 1) / WS + P_ALIGN - 1) / P_ALIGN * P_ALIGN; // stored reals per record
+    static constexpr int I_STRIDE = P_STRIDE * WS;                         // the same stride seen from the int part (irecs = recs + P_REALS)
     // fixed-point snapshot (its own buffer, touched only by arenas that ran the expensive contact paths): P + ax, ay, arot
     static constexpr int SNAP_WORDS = (P_REALS + 3 * NR) * WR, ISNAP_WORDS = 2 * NR;
     // parked mid-step state of the budgeted step (its own buffer, touched only by arenas that park): PARK_INTS ints, then
@@ -3146,7 +3157,9 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     int f0 = 0; // first sub-step to run: 0, or where a parked step goes on
     MidState mid; // (budgeted step: a sub-step parked between two passes of its resolve loop re-enters there)
     int icm = 0;  // parity build: 1 while the scratch rect is implicitly on the last ball (carry_quiet_sweep); 0: A.p.ic holds it
-    constexpr bool FZP = C::NR <= 4 && C::NB <= 8; // what the packed word holds
+    // (what the packed word holds; and not under the F32State policy: the record is rounded to fp32 between two steps, so the island a
+    // step ended with is not bit for bit the one the next step would find)
+    constexpr bool FZP = C::NR <= 4 && C::NB <= 8 && !C::MIXED;
     bool resumed = false;
     RR_T0();
     if constexpr (BUDGET) {

@@ -76,6 +76,13 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+# rr_config.dtype (include/roborugby_amd.h): "f64" = the reference's arithmetic, state and arithmetic in fp64 (parity mode, default);
+# "f32_state" = BASELINE config 2's "fp32 state": the arenas' records in HBM are fp32, a step computes in fp64 between loading a record
+# and writing it back (single steps within 1e-5 of the fp64 reference, contact steps included: tests/test_gpu_fp32.py); "f32" = state
+# and arithmetic in fp32, the fast mode (quiet steps within 1e-5, contact steps statistically).
+DTYPES = {"f64": 0, "f32": 1, "f32_state": 2}
+
+
 class BatchedRoboRugbyEnv:
     """N lockstep arenas of SimpleDuel3 on one MI355X.
 
@@ -112,6 +119,10 @@ class BatchedRoboRugbyEnv:
         if self.device.type != "cuda":
             raise ValueError("device must be a ROCm/HIP device ('cuda:N')")
         self.num_envs = int(num_envs)
+        if dtype not in DTYPES:
+            raise ValueError(f"dtype must be one of {sorted(DTYPES)}")
+        if dtype == "f32_state" and step_budget_clocks:
+            raise ValueError("dtype 'f32_state' has no budgeted step (a parked arena's record would be rounded in the middle of its step)")
         self.dtype = dtype
         self.time_limit, self.auto_reset = bool(time_limit), bool(auto_reset)
         # where the reference would raise / hang inside step() the episode ends (done=True + status bit) so that
@@ -130,7 +141,7 @@ class BatchedRoboRugbyEnv:
             nb_pos=p.nb_pos, nb_neg=p.nb_neg, arena_w=p.arena_w, arena_h=p.arena_h, game_len_steps=p.game_len_steps,
             game_mode=int(p.game_mode), time_limit=int(self.time_limit), auto_reset=int(self.auto_reset),
             reset_on_fault=int(self.reset_on_fault),
-            dtype={"f64": 0, "f32": 1}[dtype], device=self.device.index or 0, seed=int(seed),
+            dtype=DTYPES[dtype], device=self.device.index or 0, seed=int(seed),
             arena_offset=int(arena_offset), step_budget_clocks=int(step_budget_clocks), reserved_=0)
         self.step_budget_clocks = int(step_budget_clocks)
         self._bout = None  # persistent step outputs of the budgeted mode (NOT_READY rows keep their previous observation)

@@ -75,3 +75,21 @@ def score(pre, post, got, W, H):
         e = np.maximum(e, ee.reshape(len(e), -1).max(axis=1))
     ints = np.all(got["robots_i"] == post["robots_i"], axis=(1, 2))
     return q, e, ints
+
+
+def oracle_on_rounded_state(preset, pre, actions):
+    """The fp64 oracle (= the reference's arithmetic, bit for bit on tests/golden) stepping every arena of `pre` ONCE from its state
+    ROUNDED TO FP32, result rounded to fp32: what an ideal "fp32 state" implementation returns.  pre: robots [n,NR,10], robots_i,
+    balls [n,NB,8], step [n]; actions [n,NA] (-1 = no action for that robot).  Returns the state dict after the step."""
+    import oracle_lib as ol
+    r32 = lambda x: np.asarray(x, np.float64).astype(np.float32).astype(np.float64)
+    n = len(pre["step"])
+    out = {"robots": np.zeros_like(pre["robots"]), "robots_i": np.zeros_like(pre["robots_i"]), "balls": np.zeros_like(pre["balls"])}
+    for i in range(n):
+        o = ol.OracleEnv(preset)
+        o.set_state(r32(pre["robots"][i]), pre["robots_i"][i], r32(pre["balls"][i]), None, int(pre["step"][i]))
+        a = np.asarray(actions[i]); a = a[a >= 0]
+        o.step(a.astype(np.int32))
+        st = o.get_state()
+        out["robots"][i] = r32(st["robots"]); out["balls"][i] = r32(st["balls"]); out["robots_i"][i] = st["robots_i"]
+    return out

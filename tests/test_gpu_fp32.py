@@ -1,5 +1,6 @@
-"""fp32 fast mode (RR_DTYPE_F32) on the GPU against the REFERENCE's fp64 vectors and against the fp64 oracle
-(BASELINE config 2: "4,096 parallel arenas ... fp32 state"; north_star: "fp32 positions within 1e-5").
+"""The two fp32 modes on the GPU against the REFERENCE's fp64 vectors and against the fp64 oracle (BASELINE config 2: "4,096
+parallel arenas ... fp32 state"; north_star: "fp32 positions within 1e-5"): RR_DTYPE_F32_STATE (fp32 records in HBM, fp64 arithmetic
+inside a step: the reference's arithmetic on fp32 state, see _assert_state_mode) and RR_DTYPE_F32 (everything in fp32: the fast mode).
 
 Scoring is in tests/fp32_checks.py: single step from synchronised state; QUIET steps (pure kinematics) must meet
 |delta| <= 1e-5 * max(1, |x|) on every position (centre) and velocity, 1e-5 of the 360-degree range on the rotation, 1e-5 *
@@ -17,11 +18,41 @@ pytestmark = pytest.mark.gpu
 BAR = 1e-5
 
 
-def _env(preset, n, **kw):
+def _env(preset, n, dtype="f32", **kw):
     import roborugby_amd as rr
     kw.setdefault("time_limit", False)
     kw.setdefault("auto_reset", False)
-    return rr.BatchedRoboRugbyEnv(n, preset=preset, dtype="f32", **kw)
+    return rr.BatchedRoboRugbyEnv(n, preset=preset, dtype=dtype, **kw)
+
+
+def _assert_state_mode(tag, q, e, ints, done_ok, pre, post, got, cfg):
+    """dtype "f32_state" (fp32 records, fp64 arithmetic).  Two claims:
+    (1) it IS the reference's arithmetic on fp32 state: against the fp64 oracle stepping from the SAME fp32-rounded state, with its
+        result rounded to fp32, every value agrees to one fp32 ulp (the kernel's own < 1e-9 may straddle a rounding boundary) and the
+        integer state is equal;
+    (2) against the reference's UNROUNDED step the north-star bar (1e-5) holds on every quiet step with a wide margin, and on contact
+        steps the distribution is the one fp32_checks.oracle_on_rounded_state measures for the reference's own arithmetic -- rounding
+        the state to fp32 (6e-8 relative) is amplified beyond the bar by the responses of 2.9 % (T) / 10.2 % (G) of the golden contact
+        steps whoever does the arithmetic (tests/test_fp32_state_conditioning.py pins that on the CPU), so no fp32-state mode can do
+        better than this one."""
+    c = ~q
+    assert q.sum() > 100 and c.sum() > 100, (tag, int(q.sum()), int(c.sum()))
+    assert done_ok.all(), tag
+    ref = fc.oracle_on_rounded_state(tag.split()[0], pre, pre["actions"]) if "actions" in pre else None
+    beyond = float((e[c] > BAR).mean())
+    print(f"[{tag}] fp32 state / fp64 arithmetic vs the reference: {int(q.sum())} quiet steps max rel err {e[q].max():.2e}; {int(c.sum())} contact "
+          f"steps median {np.median(e[c]):.2e} p90 {np.percentile(e[c], 90):.2e} p99 {np.percentile(e[c], 99):.2e}; {100 * beyond:.2f} % beyond "
+          f"the bar, {100 * (e[c] > 1e-2).mean():.2f} % > 1e-2, integer state equal in {100 * ints[c].mean():.3f} %")
+    assert e[q].max() <= 1e-6 and ints[q].all(), (tag, float(e[q].max()))
+    assert np.median(e[c]) < 3e-7 and (e[c] > 1e-2).mean() < 0.01 and ints[c].mean() >= 0.999, tag
+    if ref is not None:
+        e_k = np.maximum(fc.rel_err(got["robots"], ref["robots"]), fc.rel_err(got["balls"], ref["balls"]))
+        same_i = np.all(got["robots_i"] == ref["robots_i"], axis=(1, 2))
+        _, e_o, _ = fc.score(pre, post, ref, cfg["W"], cfg["H"])
+        print(f"[{tag}] ... vs the oracle on the same fp32-rounded state: max rel err {e_k.max():.2e} (one fp32 ulp = 1.2e-7), integer state equal "
+              f"in {100 * same_i.mean():.3f} %; the oracle itself is beyond the bar on {100 * (e_o[c] > BAR).mean():.2f} % of the contact steps")
+        assert (e_k <= 2.5e-7).mean() >= 0.999 and same_i.mean() >= 0.999, (tag, float(e_k.max()), float(same_i.mean()))
+        assert abs((e[c] > BAR).sum() - (e_o[c] > BAR).sum()) <= max(3, 0.02 * (e_o[c] > BAR).sum()), tag
 
 
 def _assert_distribution(tag, q, e, ints, done_ok):
@@ -40,10 +71,11 @@ def _assert_distribution(tag, q, e, ints, done_ok):
           f"{100 * ints[c].mean():.2f} %")
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f32_state"])
 @pytest.mark.parametrize("preset", ["T", "G"])
-def test_f32_single_step_vs_reference_golden(golden_dir, preset):
-    """Every recorded reference step (tests/golden/traj_*.npz) replayed through an RR_DTYPE_F32 env from the reference's
-    dumped state."""
+def test_f32_single_step_vs_reference_golden(golden_dir, preset, dtype):
+    """Every recorded reference step (tests/golden/traj_*.npz) replayed through an RR_DTYPE_F32 / RR_DTYPE_F32_STATE env from the
+    reference's dumped state."""
     t = np.load(f"{golden_dir}/traj_{preset}.npz")
     cfg = ol.PRESETS[preset]
     idx = [(ep, s) for ep in range(t["length"].shape[0]) for s in range(int(t["length"][ep]))]
@@ -57,7 +89,7 @@ def test_f32_single_step_vs_reference_golden(golden_dir, preset):
     done_ok = np.zeros(n, bool)
     for k in np.unique(na_used):
         sel = np.nonzero(na_used == k)[0]
-        env = _env(preset, len(sel))
+        env = _env(preset, len(sel), dtype)
         env.set_state(pre["robots"][sel], pre["robots_i"][sel], pre["balls"][sel], pre["step"][sel])
         o, r, d, info = env.step(torch.as_tensor(acts[sel][:, :k].astype(np.int32)))
         st = env.get_state()
@@ -67,17 +99,21 @@ def test_f32_single_step_vs_reference_golden(golden_dir, preset):
         assert np.array_equal(st["step"].cpu().numpy(), post["step"][sel])
         env.close()
     q, e, ints = fc.score(pre, post, got, cfg["W"], cfg["H"])
-    _assert_distribution(f"{preset} golden", q, e, ints, done_ok)
+    if dtype == "f32_state":
+        _assert_state_mode(f"{preset} golden", q, e, ints, done_ok, dict(pre, actions=acts), post, got, cfg)
+    else:
+        _assert_distribution(f"{preset} golden", q, e, ints, done_ok)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f32_state"])
 @pytest.mark.parametrize("preset", ["T", "G"])
-def test_f32_config2_rollout_vs_f64_oracle(preset):
+def test_f32_config2_rollout_vs_f64_oracle(preset, dtype):
     """BASELINE config 2: 4,096 arenas, fp32 state, 25-step random-policy rollout.  The fp64 oracle free-runs each arena
     from the kernel's own reset; before every step the fp32 env is synchronised to the oracle's state, so each of the
     4,096 x 25 steps is a single-step comparison (chaotic dynamics: free-running fp32 and fp64 drift apart by design)."""
     n, steps, seed = 4096, 25, 5
     cfg = ol.PRESETS[preset]
-    env = _env(preset, n, seed=seed)
+    env = _env(preset, n, dtype, seed=seed)
     env.reset()
     st = {k: v.cpu().numpy() for k, v in env.get_state().items()}
     na = env.preset.nr
@@ -111,9 +147,50 @@ def test_f32_config2_rollout_vs_f64_oracle(preset):
         assert np.percentile(oe, 99) < 2e-3, float(np.percentile(oe, 99))
     q, e, ints, dn = np.concatenate(Q), np.concatenate(E), np.concatenate(I), np.concatenate(D)
     assert dn.all()
+    if dtype == "f32_state":  # (random actions from reset: the non-quiet steps are mostly near misses, few responses)
+        c = ~q
+        print(f"[{preset} config 2] fp32 state / fp64 arithmetic: {len(e)} steps vs fp64 oracle: quiet {int(q.sum())} max rel err {e[q].max():.2e}; other "
+              f"{int(c.sum())}: median {np.median(e[c]):.2e} p99 {np.percentile(e[c], 99):.2e}, {100 * (e[c] > BAR).mean():.2f} % beyond the bar")
+        # BASELINE config 2 as specified: p99 of the non-quiet steps inside the bar, < 1 % of them beyond it (measured: T p99 2.7e-6, 0.18 %; G 4.6e-6, 0.52 %)
+        assert e[q].max() <= 1e-6 and ints[q].all() and np.median(e[c]) < 3e-7, preset
+        assert np.percentile(e[c], 99) <= BAR and (e[c] > BAR).mean() < 0.01 and ints[c].mean() >= 0.999, (preset, float(np.percentile(e[c], 99)))
+        return
     assert e[q].max() <= BAR and ints[q].all(), (preset, float(e[q].max()))
     c = ~q
     # random actions rarely touch anything: the non-quiet steps here are mostly robots near walls / each other, not responses
     assert np.median(e[c]) < 1e-5 and (e[c] > 1e-2).mean() < 0.025
     print(f"[{preset} config 2] {len(e)} fp32 steps vs fp64 oracle: quiet {int(q.sum())} max rel err {e[q].max():.2e} (bar {BAR:g}); "
           f"other {int(c.sum())}: median {np.median(e[c]):.2e} p99 {np.percentile(e[c], 99):.2e}, {100 * (e[c] > 1e-2).mean():.2f} % > 1e-2")
+
+
+def test_f32_state_handle_surface():
+    """RR_DTYPE_F32_STATE: fp32 records (G 512 B per arena, T 192 B), fp64 outputs available, every side entry works; the entries that
+    would keep unrounded state across steps (rr_rollout with several steps, the step budget) refuse the handle with an error string."""
+    import roborugby_amd as rr
+    for preset, nbytes in (("G", 512), ("T", 192), ("D", 192)):
+        env = _env(preset, 256, "f32_state", seed=3)
+        assert env.state_bytes_per_env() == nbytes if preset != "D" else env.state_bytes_per_env() <= 256
+        obs = env.reset()
+        na = env.preset.nr
+        a = torch.randint(0, 8, (256, na), dtype=torch.int32, device="cuda")
+        o64, r64, d, info = env.step_f64(a)
+        assert o64.dtype == torch.float64 and bool(torch.isfinite(o64[:, :6]).all())
+        st = env.get_state()
+        # the state a step leaves behind is fp32-representable: that is the mode's definition
+        for k in ("robots", "balls"):
+            v = st[k].cpu().numpy()
+            assert np.array_equal(np.nan_to_num(v.astype(np.float32).astype(np.float64), nan=-1.0), np.nan_to_num(v, nan=-1.0)), k
+        # same state, same actions -> the fp64 handle agrees within the bar on these (mostly quiet) steps
+        ref = _env(preset, 256, "f64", seed=3)
+        ref.set_state(st["robots"], st["robots_i"], st["balls"], st["step"])
+        o_a, _, _, _ = env.step_f64(a)
+        o_b, _, _, _ = ref.step_f64(a)
+        err = (o_a - o_b).abs() / o_b.abs().clamp(min=1.0)
+        assert float(err.median()) < 1e-6
+        with pytest.raises(RuntimeError, match="F32_STATE"):
+            env.rollout(torch.zeros(4, 256, na, dtype=torch.int32, device="cuda"))
+        with pytest.raises(RuntimeError, match="F32_STATE"):
+            env.set_step_budget(100000)
+        env.close(); ref.close()
+    with pytest.raises(ValueError):
+        rr.BatchedRoboRugbyEnv(64, preset="T", dtype="f32_state", step_budget_clocks=1000)
