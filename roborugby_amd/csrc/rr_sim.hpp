@@ -437,6 +437,9 @@ template <class C> struct ArenaBody {
 #if RR_CARRY
         R ic[2];  // centre of the reference's scratch rect _rectBallInner as its last user left it ("scratch-rect carry")
 #endif
+#ifdef RR_REL_IN_RECORD // A/B builds only: the corner offsets travel with the record instead of being rebuilt by derive()
+        R rel[NR][9];
+#endif
     } p;
     struct I {
         int32_t mc[NR], thl[NR], thr[NR];
@@ -445,7 +448,9 @@ template <class C> struct ArenaBody {
     } i;
     // ---- per-step scratch
     // (rows of 9, not 8: a 16-word row stride would put every robot's row of every arena of a bank group on the same 4 banks)
+#ifndef RR_REL_IN_RECORD
     R rel[NR][9];   // corner offsets TL,TR,BL,BR (x,y) for the current rotation
+#endif
     R irot[NR];     // rotation irel was built for (NaN = stale)
     R sm[NR][4], sc[NR][4]; // slope / y-intercept of the four sides (get_slope_yint, MyUtils.py:44-58) for the current pose
     R ax[NR], ay[NR], arot[NR]; // pose at frame begin (= ring entry written this frame)
@@ -510,6 +515,11 @@ template <class C, int PAD> struct ArenaPadded : ArenaBody<C> { uint32_t lds_pad
 template <class C> struct ArenaPadded<C, 0> : ArenaBody<C> {};
 template <class C> using Arena = ArenaPadded<C, lds_pad_words((int)(sizeof(ArenaBody<C>) / 4), C::VW, (int)(sizeof(typename C::Real) / 4))>;
 
+#ifdef RR_REL_IN_RECORD
+#define RR_REL(A) (A).p.rel
+#else
+#define RR_REL(A) (A).rel
+#endif
 // ------------------------------------------------------------------------------------------------ FloatRect in registers
 template <typename R> struct FR {
     R cx, cy, l, r, t, b, rot;
@@ -577,17 +587,17 @@ template <class C> RR_HD FR<typename C::Real> load_robot(const Arena<C> &A, int 
     FR<typename C::Real> f;
     f.cx = A.p.rcx[r]; f.cy = A.p.rcy[r]; f.l = A.p.rl[r]; f.r = A.p.rrt[r]; f.t = A.p.rt[r]; f.b = A.p.rb[r];
     f.rot = A.p.rrot[r];
-    for (int k = 0; k < 8; k++) f.rel[k] = A.rel[r][k];
+    for (int k = 0; k < 8; k++) f.rel[k] = RR_REL(A)[r][k];
     return f;
 }
 template <class C> RR_HD void store_robot(Arena<C> &A, int r, const FR<typename C::Real> &f) {
     A.p.rcx[r] = f.cx; A.p.rcy[r] = f.cy; A.p.rl[r] = f.l; A.p.rrt[r] = f.r; A.p.rt[r] = f.t; A.p.rb[r] = f.b;
     A.p.rrot[r] = f.rot;
-    for (int k = 0; k < 8; k++) A.rel[r][k] = f.rel[k];
+    for (int k = 0; k < 8; k++) RR_REL(A)[r][k] = f.rel[k];
     A.sides_ok = 0;
 }
 template <class C> RR_HD V2<typename C::Real> robot_corner(const Arena<C> &A, int r, int c) {
-    V2<typename C::Real> v = { A.p.rcx[r] + A.rel[r][2 * c], A.p.rcy[r] + A.rel[r][2 * c + 1] };
+    V2<typename C::Real> v = { A.p.rcx[r] + RR_REL(A)[r][2 * c], A.p.rcy[r] + RR_REL(A)[r][2 * c + 1] };
     return v;
 }
 template <class C> RR_HD Seg<typename C::Real> robot_side(const Arena<C> &A, int r, int s) {
@@ -677,7 +687,7 @@ RR_HD void robot_move_finish(Arena<C> &A, const SimParams<typename C::Real> &sp,
             if (nr != f.rot) {
                 f.rot = nr;
                 if (nr == rot_prior) {
-                    for (int k = 0; k < 8; k++) f.rel[k] = A.rel[r][k];
+                    for (int k = 0; k < 8; k++) f.rel[k] = RR_REL(A)[r][k];
                 } else {
                     corners_for<R>(nr, (R)10, (R)20, sp.rob_cdist, f.rel);
                 }
@@ -761,7 +771,7 @@ template <class C> RR_HD bool ball_near_robot(const Arena<C> &A, int b, int r) {
     using R = typename C::Real;
     const R dx = A.p.bcx[b] - A.p.rcx[r], dy = A.p.bcy[b] - A.p.rcy[r];
     if (!(dx * dx + dy * dy <= cull_br2<R>())) return false;
-    const R *q = A.rel[r];
+    const R *q = RR_REL(A)[r];
     const R ux = (q[2] - q[0]) * (R)0.05, uy = (q[3] - q[1]) * (R)0.05;     // TL -> TR, 20 long
     const R vx = (q[4] - q[0]) * (R)0.025, vy = (q[5] - q[1]) * (R)0.025;   // TL -> BL, 40 long
     const R lx = dx * ux + dy * uy, ly = dx * vx + dy * vy;
@@ -784,7 +794,7 @@ template <class C> RR_HD bool ball_near_robot(const Arena<C> &A, int b, int r) {
 template <class C>
 RR_HD bool robots_separated(const Arena<C> &A, int i, int j, typename C::Real dx, typename C::Real dy, typename C::Real m = (typename C::Real)0.05) {
     using R = typename C::Real;
-    const R *p = A.rel[i], *q = A.rel[j];
+    const R *p = RR_REL(A)[i], *q = RR_REL(A)[j];
     // unit axes (to ~1e-15) from the corner offsets: TL -> TR is 20 long, TL -> BL 40
     const R uix = (p[2] - p[0]) * (R)0.05, uiy = (p[3] - p[1]) * (R)0.05, vix = (p[4] - p[0]) * (R)0.025, viy = (p[5] - p[1]) * (R)0.025;
     const R ujx = (q[2] - q[0]) * (R)0.05, ujy = (q[3] - q[1]) * (R)0.05, vjx = (q[4] - q[0]) * (R)0.025, vjy = (q[5] - q[1]) * (R)0.025;
@@ -1206,7 +1216,7 @@ RR_HD PrevPose<typename C::Real> robot_prev_frame(const Arena<C> &A, const SimPa
         // same rotation value as the live rect (a robot driving straight, or one that has not turned since): the setter
         // returns early and the copy keeps the live corners -- which ARE corners_for(rrot): every writer of A.rel builds
         // it with that very expression -- so no trigonometry here.  The common case of a robot pushing a ball.
-        q.tlx = A.rel[r][0]; q.tly = A.rel[r][1]; q.trx = A.rel[r][2]; q.try_ = A.rel[r][3];
+        q.tlx = RR_REL(A)[r][0]; q.tly = RR_REL(A)[r][1]; q.trx = RR_REL(A)[r][2]; q.try_ = RR_REL(A)[r][3];
     } else {
         R rel[8];
         corners_for<R>(nr, (R)10, (R)20, sp.rob_cdist, rel);
@@ -1571,7 +1581,7 @@ RR_HD void pv_robot_prev_frame(const Arena<C> &A, const SimParams<typename C::Re
     }
     const R nr = norm360<R>(rot);
     if (nr == A.p.rrot[r]) {
-        tl = pv_ld2<R>(&A.rel[r][0], 1, 0, l); tr = pv_ld2<R>(&A.rel[r][2], 1, 0, l);
+        tl = pv_ld2<R>(&RR_REL(A)[r][0], 1, 0, l); tr = pv_ld2<R>(&RR_REL(A)[r][2], 1, 0, l);
     } else {
         R rel[8];
         corners_for<R>(nr, (R)10, (R)20, sp.rob_cdist, rel);
@@ -1782,7 +1792,7 @@ RR_HDN void bounce_pass(Arena<C> &A, const SimParams<typename C::Real> &sp, uint
                         }
                     } else {
                         if ((l & (G - 1)) == 0) RR_TRACE("E bounce corner c=%d b=%d r=%d\n", cn, b, r);
-                        const PV<R> rc = pv_ld2<R>(&A.p.rcx[0], NR, r, l), ro = pv_ld2<R>(&A.rel[r][2 * cn], 1, 0, l);
+                        const PV<R> rc = pv_ld2<R>(&A.p.rcx[0], NR, r, l), ro = pv_ld2<R>(&RR_REL(A)[r][2 * cn], 1, 0, l);
                         PV<R> con, pc, sq;
                         RR_PV_EACH(i) {
                             const R bcn = rc.v[i] + ro.v[i];
@@ -2310,7 +2320,7 @@ RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, co
                     R dx = A.p.bcx[l] - A.p.rcx[r2], dy = A.p.bcy[l] - A.p.rcy[r2];
                     bool cl = dx * dx + dy * dy <= (R)(36.0 * 36.0);
                     if ((FZ || RR_BROAD_TIGHT) && PAIRED && cl) { // the robot-frame bound of ball_near_robot, grown by the same 3 px
-                        const R *q = A.rel[r2];
+                        const R *q = RR_REL(A)[r2];
                         const R ux = (q[2] - q[0]) * (R)0.05, uy = (q[3] - q[1]) * (R)0.05, vx = (q[4] - q[0]) * (R)0.025, vy = (q[5] - q[1]) * (R)0.025;
                         cl = (m_abs(dx * ux + dy * uy) <= (R)20.05) & (m_abs(dx * vx + dy * vy) <= (R)30.05);
                     }
@@ -2828,7 +2838,9 @@ template <class C> RR_HD void derive(Arena<C> &A, const SimParams<typename C::Re
     using R = typename C::Real;
     RR_FOR_LANES(l) {
         if (l < C::NR) {
-            corners_for<R>(A.p.rrot[l], (R)10, (R)20, sp.rob_cdist, A.rel[l]);
+#ifndef RR_REL_IN_RECORD
+            corners_for<R>(A.p.rrot[l], (R)10, (R)20, sp.rob_cdist, RR_REL(A)[l]);
+#endif
             A.irot[l] = (R)NAN; // inner-square offsets are built lazily by the first narrow phase that needs them
         }
     }
@@ -3159,7 +3171,11 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
     int icm = 0;  // parity build: 1 while the scratch rect is implicitly on the last ball (carry_quiet_sweep); 0: A.p.ic holds it
     // (what the packed word holds; and not under the F32State policy: the record is rounded to fp32 between two steps, so the island a
     // step ended with is not bit for bit the one the next step would find)
+#ifdef RR_NO_FZP // A/B builds only
+    constexpr bool FZP = false;
+#else
     constexpr bool FZP = C::NR <= 4 && C::NB <= 8 && !C::MIXED;
+#endif
     bool resumed = false;
     RR_T0();
     if constexpr (BUDGET) {
