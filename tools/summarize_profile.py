@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condenses a tools/r03_profile.sh (or profile_r01.sh) run (gpurun_out/prof_<tag>/) into profiles/<round>/ + profiles/traffic.json.
+"""Condenses a tools/r04_profile.sh (or profile_r01.sh) run (gpurun_out/prof_<tag>/) into profiles/<round>/ + profiles/traffic.json.
 bench.py pre-rolls a whole episode before its timed region, so the rocprofv3 stats average thousands of k_step launches; the
 summary therefore also carries the average over the LAST <timed> launches of the kernel trace (= the timed region bench.py's own
 HIP events bracket) -- the number that has to agree with the bench line's roofline.kernel_ms.
@@ -66,6 +66,6 @@ json.dump(out, open(f"{out_dir}/{key}_summary.json", "w"), indent=1)
 tf = "profiles/traffic.json"
 t = json.load(open(tf)) if os.path.exists(tf) else {}
 t[key] = {"bytes": 2 * f_ + w_, "source": f"{out_dir}/{key}_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, "
-                                            f"tools/r03_profile.sh {tag})"}
+                                            f"tools/r04_profile.sh {tag})"}
 json.dump(t, open(tf, "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("avg_ns", "hbm_bytes_per_env_step")}))
