@@ -443,6 +443,9 @@ int rr_dqn_create(int32_t device, rr_dqn **out) {
     hipDeviceProp_t prop;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    // RR_DQN_WGS: workgroups of the update / act kernels (default: one per CU).  A workgroup takes a whole CU (every register, 143 KB of
+    // LDS), so fewer of them leave CUs to whatever runs on another stream -- config 5 steps the simulator there (roborugby_amd/dqn.py)
+    { const char *w = getenv("RR_DQN_WGS"); const int k = w ? atoi(w) : 0; if (k > 0 && k < cus) cus = k; }
     rr_dqn *d = new rr_dqn();
     d->device = device; d->nwg = cus; d->step = 0; d->partials = nullptr; d->m1 = nullptr; d->m2 = nullptr;
     d->chunk_off = nullptr; d->chunk_cap = 0;
