@@ -388,7 +388,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "peak_measured": peak_measured,
                          "peak_measured_how": "device-to-device copy of 1 GiB, read + write bytes / HIP-event time, this run: the better of the "
-                                              "library's 16-B-per-lane grid-stride kernel (rr_probe_hbm_copy) and torch's copy_",
+                                              "library's one-16-B-element-per-thread copy kernel (rr_probe_hbm_copy) and torch's copy_",
                          "peak_measured_copy_kernel": peak_kernel, "peak_measured_torch_copy": peak_torch,
                          "kernel": "k_step", "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": bytes_per_step,
                          "record_bytes_per_env": env.state_bytes_per_env(),

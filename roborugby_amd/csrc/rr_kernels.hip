@@ -321,21 +321,15 @@ __global__ void k_policy_chase(const float *obs, int n, int na, uint32_t noise_u
     for (int k = 1; k < na; k++) actions[(size_t)a * na + k] = (int)((c[2 + (k & 1)] >> (4 * (k >> 1))) & 7u);
 }
 
-// HBM copy probe ("confirm on the box with a hipMemcpyDtoD / stream-triad probe"): a plain 16-B-per-lane
-// grid-stride copy, the access pattern MI355X_MICROARCH.md quotes its ~6.3 TB/s for.  bench.py times it with HIP events and
-// reports read + write bytes per second next to the 8 TB/s spec (roofline.peak_measured).
+// HBM copy probe ("confirm on the box with a hipMemcpyDtoD / stream-triad probe"): ONE 16-byte element per
+// thread, one workgroup per 4 KB, no loop -- the shape MI355X_MICROARCH.md quotes its ~6.3 TB/s for.  Measured on the MI355X
+// (tools/probes/hbm_copy_probe.hip, profiles/r04/hbm_copy_probe.txt, 1 GiB, read + write bytes): this 6.15 TB/s; grid-stride loops
+// with 1-8 elements in flight per lane 4.3-5.7 TB/s (the round-3 probe was one of those: 4.66); hipMemcpyDtoD 5.19.  bench.py times
+// it with HIP events and reports it next to the 8 TB/s spec (roofline.peak_measured).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_copy16(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, size_t n16) {
-    // four independent 16-B loads in flight per lane, then the four stores (a wavefront moves 4 KB per round)
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const u32x4 a = __builtin_nontemporal_load(&src[i]), b = __builtin_nontemporal_load(&src[i + stride]);
-        const u32x4 c = __builtin_nontemporal_load(&src[i + 2 * stride]), d = __builtin_nontemporal_load(&src[i + 3 * stride]);
-        __builtin_nontemporal_store(a, &dst[i]); __builtin_nontemporal_store(b, &dst[i + stride]);
-        __builtin_nontemporal_store(c, &dst[i + 2 * stride]); __builtin_nontemporal_store(d, &dst[i + 3 * stride]);
-    }
-    for (; i < n16; i += stride) dst[i] = src[i];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -956,8 +950,8 @@ int rr_probe_hbm_copy(void *dst, const void *src, size_t bytes, void *stream) {
     if (!dst || !src || bytes < 16 || (bytes & 15) || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15))
         return fail(-1, "rr_probe_hbm_copy: 16-byte aligned buffers and a multiple of 16 bytes, please");
     const size_t n16 = bytes / 16;
-    size_t blocks = (n16 + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16; // 16 workgroups per CU, grid-stride over the rest
+    const size_t blocks = (n16 + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return fail(-1, "rr_probe_hbm_copy: at most 8 TiB per call");
     hipLaunchKernelGGL(k_copy16, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4 *)src, (u32x4 *)dst, n16);
     HIP_TRY(hipGetLastError());
     return 0;
