@@ -59,7 +59,9 @@ typedef struct rr_env rr_env; /* opaque */
 typedef struct rr_config {
     int32_t struct_size;    /* = sizeof(rr_config), for forward compatibility                          */
     int32_t num_envs;       /* N arenas stepped in lockstep by this handle                             */
-    int32_t nr_happy, nr_grumpy, nb_pos, nb_neg; /* RR_Constants.py:30-34; built shapes: (1,0,1,0), (2,2,4,4), (1,1,1,1) */
+    int32_t nr_happy, nr_grumpy, nb_pos, nb_neg; /* RR_Constants.py:30-34; shapes inside libroborugby_amd.so: (1,0,1,0), (2,2,4,4), (1,1,1,1);
+                                                    any other counts (<= 8 robots, <= 11 balls, <= 32 ball-robot pairs): a one-shape library of the same
+                                                    sources and ABI, hipcc -DRR_CUSTOM_SHAPE ... (roborugby_amd/build.py: build_shape_library) */
     double arena_w, arena_h;                     /* RR_Constants.py:6-7                                */
     int32_t game_len_steps; /* RR_Constants.py:25                                                      */
     int32_t game_mode;      /* RR_Constants.py:4: only selects the undo-loop fault rule (EnvBase:417-421) */

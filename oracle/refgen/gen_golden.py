@@ -241,8 +241,8 @@ def gen_traj(R, preset):
     env = R.envs.SimpleDuel3()
     reset_scratch_rect(R)
     NR = len(env.lstRobots)
-    rng = random.Random({"G": 20201, "T": 20202, "D": 20203}[preset])
-    if preset == "D":  # two robots (one per team), two balls (one of each colour), G's arena and episode length
+    rng = random.Random({"G": 20201, "T": 20202, "D": 20203, "X": 20204}[preset])
+    if preset in ("D", "X"):  # two robots (one per team), two balls (one of each colour), G's arena and episode length
         plan = [("random", NR, 150, False, 0), ("chase", NR, 300, False, 0), ("chase_noisy", NR, 300, True, 6.0),
                 ("chase", NR, 300, True, 9.0), ("forward", NR, 200, True, 3.0), ("chase", 1, 300, True, 5.0),
                 ("chase_noisy", NR, 300, True, 12.0), ("chase", NR, 300, True, 2.0), ("random", NR, 200, True, 10.0),
@@ -694,7 +694,7 @@ def gen_mix(R, preset):
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which == "all":
-        for p in ("T", "G", "D"):
+        for p in ("T", "G", "D", "X"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), p])
         return
     from load_reference import load_reference

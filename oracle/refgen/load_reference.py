@@ -6,7 +6,8 @@ box).  One preset per process: the reference's constants are module globals
 RR_Constants.py with that one assignment flipped into a module object that is
 registered before anything else imports it.  Preset D (the 1+1 / 1+1 duel) keeps
 GAME_MODE = True and sets the four entity counts of RR_Constants.py:30-34 to 1 the
-same way.  Nothing on disk changes.
+same way; preset X sets them to 2 + 1 robots and 2 + 3 balls (a shape outside the
+library's built list: odd counts, unequal teams).  Nothing on disk changes.
 """
 import os
 import sys
@@ -21,7 +22,7 @@ def reference_available():
 
 def load_reference(preset):
     """Returns a namespace with the reference modules for preset 'G' or 'T'."""
-    assert preset in ("G", "T", "D")
+    assert preset in ("G", "T", "D", "X")
     if not reference_available():
         raise RuntimeError("reference tree not present at %s" % REF_ROOT)
     sys.dont_write_bytecode = True
@@ -34,10 +35,10 @@ def load_reference(preset):
         sys.path.insert(0, REF_ROOT)
     if "robo_rugby.gym_env.RR_Constants" in sys.modules:
         const = sys.modules["robo_rugby.gym_env.RR_Constants"]
-        have = ("G" if const.NUM_ROBOTS_TOTAL == 4 else "D") if const.GAME_MODE else "T"
+        have = {4: "G", 2: "D", 3: "X"}[const.NUM_ROBOTS_TOTAL] if const.GAME_MODE else "T"
         if have != preset:
             raise RuntimeError("reference already loaded with preset %s in this process" % have)
-    elif preset in ("T", "D"):
+    elif preset in ("T", "D", "X"):
         pkg = types.ModuleType("robo_rugby")
         pkg.__path__ = [os.path.join(REF_ROOT, "robo_rugby")]
         sub = types.ModuleType("robo_rugby.gym_env")
@@ -47,12 +48,14 @@ def load_reference(preset):
         if preset == "T":
             assert text.count("GAME_MODE = True") == 1
             text = text.replace("GAME_MODE = True", "GAME_MODE = False", 1)
-        else:  # the duel: one robot per team, one ball of each colour
+        else:  # D, the duel: one robot per team, one ball of each colour; X: 2 + 1 robots, 2 + 3 balls
+            want = dict(NUM_BALL_POS=1, NUM_BALL_NEG=1, NUM_ROBOTS_HAPPY=1, NUM_ROBOTS_GRUMPY=1) if preset == "D" else \
+                dict(NUM_BALL_POS=2, NUM_BALL_NEG=3, NUM_ROBOTS_HAPPY=2, NUM_ROBOTS_GRUMPY=1)
             for name, was in (("NUM_BALL_POS", "4 if GAME_MODE else 1"), ("NUM_BALL_NEG", "4 if GAME_MODE else 0"),
                               ("NUM_ROBOTS_HAPPY", "2 if GAME_MODE else 1"), ("NUM_ROBOTS_GRUMPY", "2 if GAME_MODE else 0")):
                 line = f"{name} = {was}"
                 assert text.count(line) == 1, line
-                text = text.replace(line, f"{name} = 1", 1)
+                text = text.replace(line, f"{name} = {want[name]}", 1)
         const = types.ModuleType("robo_rugby.gym_env.RR_Constants")
         const.__file__ = path
         exec(compile(text, path, "exec"), const.__dict__)
@@ -70,8 +73,8 @@ def load_reference(preset):
     import robo_rugby.gym_env.RR_Goal as goal
     import robo_rugby.gym_env.RR_ScoreKeepers as sk
     import robo_rugby.gym_env.RR_Observers as obs
-    assert bool(const.GAME_MODE) == (preset in ("G", "D"))
-    assert const.NUM_ROBOTS_TOTAL == {"G": 4, "T": 1, "D": 2}[preset]
+    assert bool(const.GAME_MODE) == (preset in ("G", "D", "X"))
+    assert const.NUM_ROBOTS_TOTAL == {"G": 4, "T": 1, "D": 2, "X": 3}[preset]
     ns = types.SimpleNamespace(MyUtils=MyUtils, const=const, base=base, tp=tp, envs=envs, robot=robot,
                                ball=ball, goal=goal, sk=sk, obs=obs, preset=preset)
     return ns

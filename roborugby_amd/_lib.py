@@ -103,6 +103,35 @@ def load(exact=False):
     return _lib
 
 
+_shape_libs = {}
+
+
+def load_shape(counts, exact=False):
+    """The one-shape library of entity counts outside the built list (build.build_shape_library), compiled on demand when it is missing
+    or older than its sources -- hipcc has to be there for that; the same ABI, no fallback of any kind."""
+    from . import build as _build
+    key = (tuple(int(c) for c in counts), bool(exact))
+    if key not in _shape_libs:
+        path = _build.shape_lib_path(*key[0], exact=exact)
+        if _build.shape_is_stale(*key[0], exact=exact) and (_build.sources_present() or not os.path.exists(path)):
+            try:
+                _build.build_shape_library(*key[0], verbose=True, exact=exact)
+            except Exception as exc:
+                raise ImportError(f"{path}: no library for {key[0][0]}+{key[0][1]} robots / {key[0][2]}+{key[0][3]} balls and it could not be "
+                                  f"built ({exc}): `python -m roborugby_amd.build --shape={','.join(map(str, key[0]))}` needs hipcc") from exc
+        _shape_libs[key] = _bind(C.CDLL(path), exact, False, path)
+    return _shape_libs[key]
+
+
+def _bind(lib, exact, overridden, path):
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    assert lib.rr_exact_trig() == (1 if exact else 0) or overridden, path
+    return lib
+
+
 def _load_path(path, exact):
     from . import build as _build
     overridden = not exact and "RR_LIB_PATH" in os.environ
@@ -120,13 +149,7 @@ def _load_path(path, exact):
             raise ImportError(
                 f"{path} is missing and could not be built ({exc}): run `python -m roborugby_amd.build`. "
                 "roborugby_amd has no CPU fallback.") from exc
-    lib = C.CDLL(path)
-    for name, (res, args) in SYMBOLS.items():
-        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
-        fn.restype = res
-        fn.argtypes = args
-    assert lib.rr_exact_trig() == (1 if exact else 0) or overridden, path
-    return lib
+    return _bind(C.CDLL(path), exact, overridden, path)
 
 
 class RRError(RuntimeError):

@@ -90,8 +90,64 @@ def build_hip_library(force=False, verbose=False, jobs=None, exact=False):
     return lib_path
 
 
+# ---- one-shape libraries: entity counts outside the built list (the reference's counts are free integers, RR_Constants.py:30-34)
+SHAPES_DIR = os.path.join(HERE, "shapes")
+BUILT_SHAPES = {(1, 0, 1, 0), (2, 2, 4, 4), (1, 1, 1, 1)}  # inside libroborugby_amd.so (csrc/rr_kstep.hpp: RR_FOR_EACH_CFG)
+
+
+def shape_lanes(nrh, nrg, nbp, nbn):
+    """lanes per arena of a one-shape library: one lane per entity, a power of two >= 2; raises for counts the phases' masks cannot hold"""
+    nr, nb = nrh + nrg, nbp + nbn
+    if min(nrh, nrg, nbp, nbn) < 0 or nrh < 1 or nb < 1 or nbp < 1:
+        raise ValueError("at least one happy robot and one positive ball (the observation and the rewards are built around them)")
+    if nr > 8 or nb > 11 or nr * nb > 32:
+        raise ValueError(f"{nr} robots x {nb} balls: the contact masks hold at most 8 robots, 11 balls and 32 ball-robot pairs per arena")
+    vw = 2
+    while vw < max(nr, nb):
+        vw *= 2
+    return vw
+
+
+def shape_lib_path(nrh, nrg, nbp, nbn, exact=False):
+    return os.path.join(SHAPES_DIR, f"libroborugby_amd_{nrh}x{nrg}_{nbp}x{nbn}{'_exact' if exact else ''}.so")
+
+
+def shape_is_stale(nrh, nrg, nbp, nbn, exact=False):
+    lib = shape_lib_path(nrh, nrg, nbp, nbn, exact)
+    if not os.path.exists(lib) or not os.path.exists(lib + ".srchash"):
+        return True
+    with open(lib + ".srchash") as f:
+        return f.read().strip() != source_hash()
+
+
+def build_shape_library(nrh, nrg, nbp, nbn, force=False, verbose=False, exact=False):
+    """hipcc ... -DRR_CUSTOM_SHAPE -> roborugby_amd/shapes/libroborugby_amd_<nrh>x<nrg>_<nbp>x<nbn>.so: the same sources and ABI for ONE
+    shape (fp64 and fp32-state precisions, every k_step variant), one translation unit, a minute or two of hipcc for G-sized shapes."""
+    vw = shape_lanes(nrh, nrg, nbp, nbn)
+    lib_path = shape_lib_path(nrh, nrg, nbp, nbn, exact)
+    if not force and not shape_is_stale(nrh, nrg, nbp, nbn, exact):
+        return lib_path
+    os.makedirs(SHAPES_DIR, exist_ok=True)
+    digest = source_hash()
+    tmp = lib_path + f".tmp{os.getpid()}"
+    cmd = [find_hipcc()] + HIPCC_FLAGS + (["-DRR_EXACT_TRIG=1"] if exact else []) + [
+        "-DRR_CUSTOM_SHAPE", "-DRR_CFG_SUBSET=9", f"-DRR_NRH={nrh}", f"-DRR_NRG={nrg}", f"-DRR_NBP={nbp}", f"-DRR_NBN={nbn}", f"-DRR_CVW={vw}",
+        "-o", tmp, SRC, SRC_DQN]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    os.replace(tmp, lib_path)
+    with open(lib_path + ".srchash", "w") as f:
+        f.write(digest + "\n")
+    return lib_path
+
+
 if __name__ == "__main__":  # python -m roborugby_amd.build [--force]: rebuilds what is stale (everything with --force)
     import sys
     _force = "--force" in sys.argv[1:]
-    print(build_hip_library(force=_force, verbose=True))
-    print(build_hip_library(force=_force, verbose=True, exact=True))
+    _shape = [a for a in sys.argv[1:] if a.startswith("--shape=")]  # --shape=NRH,NRG,NBP,NBN: a one-shape library instead
+    if _shape:
+        print(build_shape_library(*[int(x) for x in _shape[0].split("=")[1].split(",")], force=_force, verbose=True))
+    else:
+        print(build_hip_library(force=_force, verbose=True))
+        print(build_hip_library(force=_force, verbose=True, exact=True))

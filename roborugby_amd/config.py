@@ -53,7 +53,20 @@ PRESETS = {
     "G": Preset("G", True, 800.0, 800.0, 2, 2, 4, 4, 30, int(2.5 * 60 * 30)),
     "T": Preset("T", False, 600.0, 600.0, 1, 0, 1, 0, 30, int(10 / 60 * 60 * 30)),
     "D": Preset("D", True, 800.0, 800.0, 1, 1, 1, 1, 30, int(2.5 * 60 * 30)),
+    # NOT one of the shapes inside libroborugby_amd.so: the reference's entity counts are free integers (RR_Constants.py:30-34), and any
+    # other counts run through a one-shape library compiled on demand (build.build_shape_library).  X -- 2 + 1 robots, 2 + 3 balls, G's
+    # other constants -- is the one the tests pin to reference vectors (tests/golden/{traj,reset}_X.npz); custom_preset() makes more.
+    "X": Preset("X", True, 800.0, 800.0, 2, 1, 2, 3, 30, int(2.5 * 60 * 30)),
 }
+
+
+def custom_preset(nr_happy, nr_grumpy, nb_pos, nb_neg, game_mode=True, name=None):
+    """A preset with the reference's other constants of GAME_MODE=True / False (RR_Constants.py:6-7,24-25) and these entity counts
+    (RR_Constants.py:30-34): pass it as `preset=`; the env loads (or compiles, hipcc permitting) the one-shape library for it."""
+    base = PRESETS["G" if game_mode else "T"]
+    return Preset(name or f"{nr_happy}+{nr_grumpy}/{nb_pos}+{nb_neg}", bool(game_mode), base.arena_w, base.arena_h, int(nr_happy), int(nr_grumpy),
+                  int(nb_pos), int(nb_neg), base.framerate, base.game_len_steps)
+
 
 ROBOT_LENGTH, ROBOT_WIDTH = 20, 40  # RR_Constants.py:8-9
 BALL_RADIUS = 7

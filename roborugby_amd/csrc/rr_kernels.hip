@@ -416,10 +416,17 @@ int rr_create(const rr_config *cfg, rr_env **out) {
     if (cfg->struct_size != (int32_t)sizeof(rr_config)) return fail(-1, "rr_create: rr_config.struct_size mismatch");
     if (cfg->num_envs <= 0) return fail(-1, "rr_create: num_envs must be positive");
     int shape;
+#if defined(RR_CUSTOM_SHAPE)
+    if (cfg->nr_happy == RR_NRH && cfg->nr_grumpy == RR_NRG && cfg->nb_pos == RR_NBP && cfg->nb_neg == RR_NBN) shape = 0;
+    else return fail(-1, "rr_create: this library was built for one shape only (roborugby_amd.build.build_shape_library) and it is not this one");
+    if (cfg->dtype == RR_DTYPE_F32) return fail(-1, "rr_create: a one-shape library is built for RR_DTYPE_F64 and RR_DTYPE_F32_STATE only");
+#else
     if (cfg->nr_happy == 1 && cfg->nr_grumpy == 0 && cfg->nb_pos == 1 && cfg->nb_neg == 0) shape = 0;
     else if (cfg->nr_happy == 2 && cfg->nr_grumpy == 2 && cfg->nb_pos == 4 && cfg->nb_neg == 4) shape = 1;
     else if (cfg->nr_happy == 1 && cfg->nr_grumpy == 1 && cfg->nb_pos == 1 && cfg->nb_neg == 1) shape = 2;
-    else return fail(-1, "rr_create: unsupported entity counts (built shapes: 1+0 robots/1+0 balls, 2+2 robots/4+4 balls, 1+1 robots/1+1 balls)");
+    else return fail(-1, "rr_create: unsupported entity counts (built shapes: 1+0 robots/1+0 balls, 2+2 robots/4+4 balls, 1+1 robots/1+1 balls; "
+                         "any other counts: a one-shape library, roborugby_amd.build.build_shape_library / BatchedRoboRugbyEnv does it on demand)");
+#endif
     if (cfg->dtype != RR_DTYPE_F64 && cfg->dtype != RR_DTYPE_F32 && cfg->dtype != RR_DTYPE_F32_STATE) return fail(-1, "rr_create: bad dtype");
     if (cfg->dtype == RR_DTYPE_F32_STATE && cfg->step_budget_clocks) return fail(-1, "rr_create: no step budget with RR_DTYPE_F32_STATE");
     if (!(cfg->arena_w >= 300 && cfg->arena_h >= 300 && cfg->arena_w <= 8192 && cfg->arena_h <= 8192))

@@ -148,7 +148,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
 // arithmetic (rr_sim.hpp: F32State; default lane widths only, no budgeted / multi-step variant); shapes: 0 = T (1+0 robots, 1+0 balls), 1 = G (2+2, 4+4),
 // 2 = D (1+1 robots, 1+1 balls: the two-team duel).  The first VW listed for a kind is the default; the environment variable
 // RR_VW selects another built width (kernel tuning / A-B runs).
-#if defined(RR_CFG_SUBSET) && RR_CFG_SUBSET == 2 // occupancy probe: T at 4 lanes per arena (its LDS admits 4 waves per SIMD)
+#if defined(RR_CUSTOM_SHAPE)
+// A library for ONE shape outside the built list (roborugby_amd.build.build_shape_library: the reference's entity counts are free
+// integers, RR_Constants.py:30-34): -DRR_CUSTOM_SHAPE -DRR_NRH= -DRR_NRG= -DRR_NBP= -DRR_NBN= -DRR_CVW=<lanes per arena> (+ RR_CFG_SUBSET:
+// one translation unit, implicit instantiation).  Precisions: fp64 and fp32 state / fp64 arithmetic.
+#define RR_FOR_EACH_CFG(X) X(0, RR_NRH, RR_NRG, RR_NBP, RR_NBN, double, RR_CVW) X(6, RR_NRH, RR_NRG, RR_NBP, RR_NBN, F32State, RR_CVW)
+#elif defined(RR_CFG_SUBSET) && RR_CFG_SUBSET == 2 // occupancy probe: T at 4 lanes per arena (its LDS admits 4 waves per SIMD)
 #define RR_FOR_EACH_CFG(X) X(0, 1, 0, 1, 0, double, 4) X(1, 2, 2, 4, 4, double, 8)
 #elif defined(RR_CFG_SUBSET) && RR_CFG_SUBSET == 3 // tuning builds of the duel shape
 #define RR_FOR_EACH_CFG(X) X(2, 1, 1, 1, 1, double, 4) X(1, 2, 2, 4, 4, double, 8)
@@ -166,7 +171,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, lds_waves_per_simd<C>()) void
 #endif
 constexpr int RR_NUM_SHAPES = 3;
 // default lanes per arena of a shape (the widths rr_rollout's multi-step variant is built for)
+#if defined(RR_CUSTOM_SHAPE)
+template <class C> constexpr int default_vw() { return RR_CVW; }
+#else
 template <class C> constexpr int default_vw() { return C::NR == 1 ? 2 : C::NR == 2 ? 4 : 8; }
+#endif
 
 // ---- split build: the same list once more, with the translation unit (part) each configuration's k_step instantiations are
 // compiled in -- G kernels are the slow ones to compile, so they are spread first.  X(part, NRH, NRG, NBP, NBN, Real, VW, DEF)

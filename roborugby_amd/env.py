@@ -135,7 +135,14 @@ class BatchedRoboRugbyEnv:
         self.exact_trig = bool(exact_trig)
         if self.exact_trig and dtype != "f64":
             raise ValueError("exact_trig is a property of the fp64 parity mode")
-        self._lib = _lib.load(exact=self.exact_trig)
+        counts = (p.nr_happy, p.nr_grumpy, p.nb_pos, p.nb_neg)
+        from . import build as _build
+        if counts in _build.BUILT_SHAPES:
+            self._lib = _lib.load(exact=self.exact_trig)
+        else:  # the reference's entity counts are free integers (RR_Constants.py:30-34): a library for this one shape, compiled on demand
+            if dtype == "f32":
+                raise ValueError("entity counts outside the built shapes: dtype 'f64' or 'f32_state'")
+            self._lib = _lib.load_shape(counts, exact=self.exact_trig)
         cfg = _lib.RRConfig(
             struct_size=C.sizeof(_lib.RRConfig), num_envs=self.num_envs, nr_happy=p.nr_happy, nr_grumpy=p.nr_grumpy,
             nb_pos=p.nb_pos, nb_neg=p.nb_neg, arena_w=p.arena_w, arena_h=p.arena_h, game_len_steps=p.game_len_steps,

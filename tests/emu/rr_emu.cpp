@@ -94,6 +94,10 @@ typedef Cfg<2, 2, 4, 4, double, 16> CG64n;
 typedef Cfg<1, 1, 1, 1, double, 64> CD64;
 typedef Cfg<1, 1, 1, 1, float, 64> CD32;
 typedef Cfg<1, 1, 1, 1, double, 4> CD64n;
+// a shape that is NOT one of the library's built ones (2+1 robots, 2+3 balls: odd counts, unequal teams): what build_shape_library
+// compiles on demand (roborugby_amd/build.py); one lane per entity needs 8 lanes
+typedef Cfg<2, 1, 2, 3, double, 64> CX64;
+typedef Cfg<2, 1, 2, 3, double, 8> CX64n;
 
 struct Handle { int kind; void *p; };
 
@@ -108,6 +112,8 @@ struct Handle { int kind; void *p; };
     case 6: { auto *e = (Emu<CD64> *)(h)->p; typedef CD64 CC; __VA_ARGS__; } break; \
     case 7: { auto *e = (Emu<CD32> *)(h)->p; typedef CD32 CC; __VA_ARGS__; } break; \
     case 8: { auto *e = (Emu<CD64n> *)(h)->p; typedef CD64n CC; __VA_ARGS__; } break; \
+    case 9: { auto *e = (Emu<CX64> *)(h)->p; typedef CX64 CC; __VA_ARGS__; } break; \
+    case 10: { auto *e = (Emu<CX64n> *)(h)->p; typedef CX64n CC; __VA_ARGS__; } break; \
     }
 
 extern "C" {
@@ -126,8 +132,10 @@ void emu_sincos(double x, double *s, double *c) { m_sincos(x, *s, *c); }
 Handle *emu_create(int preset, int f32, double W, double H, int game_len, int game_mode, int time_limit, int auto_reset,
                    uint64_t seed) {
     Handle *h = new Handle;
-    h->kind = preset == 2 ? 6 + f32 : preset + 2 * f32;
+    h->kind = preset == 3 ? (f32 == 2 ? 10 : 9) : preset == 2 ? 6 + f32 : preset + 2 * f32; // preset 3 = X (fp64 only)
     switch (h->kind) {
+    case 9: h->p = calloc(1, sizeof(Emu<CX64>)); break;
+    case 10: h->p = calloc(1, sizeof(Emu<CX64n>)); break;
     case 6: h->p = calloc(1, sizeof(Emu<CD64>)); break;
     case 7: h->p = calloc(1, sizeof(Emu<CD32>)); break;
     case 8: h->p = calloc(1, sizeof(Emu<CD64n>)); break;

@@ -16,6 +16,8 @@ PRESETS = {  # RR_Constants.py:6-7,24-25,30-34
     "G": dict(nr_h=2, nr_g=2, nb_p=4, nb_n=4, W=800.0, H=800.0, game_len=4500, game_mode=1),
     "T": dict(nr_h=1, nr_g=0, nb_p=1, nb_n=0, W=600.0, H=600.0, game_len=300, game_mode=0),
     "D": dict(nr_h=1, nr_g=1, nb_p=1, nb_n=1, W=800.0, H=800.0, game_len=4500, game_mode=1),  # the duel: G's constants, one entity each
+    # a shape outside the library's built list (compiled on demand: roborugby_amd.build.build_shape_library): odd counts, unequal teams
+    "X": dict(nr_h=2, nr_g=1, nb_p=2, nb_n=3, W=800.0, H=800.0, game_len=4500, game_mode=1),
 }
 
 

@@ -43,7 +43,8 @@ def _compare(preset, res, st, r_res, r_st, ctx, inputs=None):
     return "ok"
 
 
-@pytest.mark.parametrize("preset,n,narrow", [("T", 360, False), ("T", 240, True), ("G", 150, False), ("G", 150, True), ("D", 240, False), ("D", 180, True)])
+@pytest.mark.parametrize("preset,n,narrow", [("T", 360, False), ("T", 240, True), ("G", 150, False), ("G", 150, True), ("D", 240, False), ("D", 180, True),
+                                                  ("X", 200, False), ("X", 200, True)])
 def test_emulated_kernel_vs_oracle_on_adversarial_states(preset, n, narrow):
     robots, balls, actions = adv.make_states(preset, n, seed=11 + int(narrow))
     env = el.EmuEnv(preset, narrow=narrow)
@@ -64,7 +65,8 @@ def test_emulated_kernel_vs_oracle_on_adversarial_states(preset, n, narrow):
           f"{knife} on a knife edge of the reference itself")
 
 
-@pytest.mark.parametrize("preset,n,narrow", [("T", 900, False), ("T", 600, True), ("G", 160, False), ("G", 120, True), ("D", 400, False), ("D", 300, True)])
+@pytest.mark.parametrize("preset,n,narrow", [("T", 900, False), ("T", 600, True), ("G", 160, False), ("G", 120, True), ("D", 400, False), ("D", 300, True),
+                                                  ("X", 240, False), ("X", 200, True)])
 def test_emulated_kernel_vs_oracle_on_balls_around_robot_corners(preset, n, narrow):
     """the broad phase's corner-zone bound (ball_near_robot) must not drop a hit: balls at 6.4-7.7 px from robot corners"""
     robots, balls, actions = adv.make_corner_states(preset, n, seed=3 + int(narrow))
@@ -83,7 +85,8 @@ def test_emulated_kernel_vs_oracle_on_balls_around_robot_corners(preset, n, narr
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("preset,n,gen", [("T", 6000, "mixed"), ("G", 3000, "mixed"), ("T", 5000, "corners"), ("G", 1500, "corners"), ("D", 4000, "mixed"), ("D", 2500, "corners")])
+@pytest.mark.parametrize("preset,n,gen", [("T", 6000, "mixed"), ("G", 3000, "mixed"), ("T", 5000, "corners"), ("G", 1500, "corners"), ("D", 4000, "mixed"), ("D", 2500, "corners"),
+                                          ("X", 3000, "mixed"), ("X", 1500, "corners")])
 def test_gpu_kernel_vs_oracle_on_adversarial_states(preset, n, gen):
     import torch
     import roborugby_amd as rr

@@ -66,7 +66,7 @@ def _drive(env, t, ep, s):
     return env.step(acts[acts >= 0])
 
 
-@pytest.mark.parametrize("preset", ["T", "G", "D"])
+@pytest.mark.parametrize("preset", ["T", "G", "D", "X"])
 def test_trajectories_bit_exact(golden_dir, preset):
     t = np.load(f"{golden_dir}/traj_{preset}.npz")
     total = 0
@@ -77,7 +77,7 @@ def test_trajectories_bit_exact(golden_dir, preset):
     # the fixtures really exercise every response path of the hot loop
     for k in ("apply_force_to_ball", "bounce_ball_off_bot", "bounce_ball_off_wall", "undo_naughty"):
         assert cov[k] > 0, k
-    if preset == "G":
+    if preset in ("G", "X"):
         assert cov["bounce_balls"] > 0 and cov["robot_collision"] > 0
 
 
@@ -97,7 +97,7 @@ def test_thrust_entry_bit_exact(golden_dir, preset):
     assert cov["apply_force_to_ball"] > 0 and cov["bounce_ball_off_bot"] > 0 and cov["bounce_ball_off_wall"] > 0
 
 
-@pytest.mark.parametrize("preset", ["T", "G", "D"])
+@pytest.mark.parametrize("preset", ["T", "G", "D", "X"])
 def test_done_flag_is_step_counter(golden_dir, preset):
     """done = lngStepCount > GAME_LENGTH_STEPS (RR_EnvBase.py:555-559); stepping after done is flagged."""
     cfg = ol.PRESETS[preset]

@@ -24,7 +24,7 @@ def oracle_layouts(preset, arenas, episodes, seed=2024):
     return np.array(R), np.array(B)
 
 
-@pytest.mark.parametrize("preset", ["T", "G", "D"])
+@pytest.mark.parametrize("preset", ["T", "G", "D", "X"])
 def test_reference_layouts_satisfy_the_oracles_rejection_rule_and_first_obs(golden_dir, preset):
     """Every layout the REFERENCE produced, rebuilt in the oracle (clean rects at the reference's x, y, rot): no int-AABB
     overlap under the oracle's rect arithmetic -- i.e. oracle and reference agree on what `spritecollide` rejects -- and
@@ -46,7 +46,7 @@ def test_reference_layouts_satisfy_the_oracles_rejection_rule_and_first_obs(gold
     rc.check_support(R, B, cfg["W"], cfg["H"], need_endpoints=False)
 
 
-@pytest.mark.parametrize("preset,arenas,episodes", [("T", 2000, 50), ("G", 1000, 100), ("D", 2000, 50)])
+@pytest.mark.parametrize("preset,arenas,episodes", [("T", 2000, 50), ("G", 1000, 100), ("D", 2000, 50), ("X", 1000, 100)])
 def test_oracle_reset_distribution_matches_reference(golden_dir, preset, arenas, episodes):
     t = np.load(f"{golden_dir}/reset_{preset}.npz")
     cfg = ol.PRESETS[preset]
