@@ -42,7 +42,7 @@ def test_emulated_kernel_vs_reference_golden(golden_dir, preset, stride, narrow)
     print(f"[{preset}] {n} golden steps through the emulated wave, worst {worst:.2e}")
 
 
-@pytest.mark.parametrize("preset", ["T", "G", "D"])
+@pytest.mark.parametrize("preset", ["T", "G", "D", "X"])
 def test_emulated_kernel_thrust_entry_vs_reference_golden(golden_dir, preset):
     """The kernel's continuous-thrust entry (rr_step_thrust's path in step_arena) against the reference's own
     GameEnv.step vectors (tests/golden/thrust_*.npz: half-way rounding cases, |thrust| up to 3, fewer pairs than robots)."""

@@ -81,7 +81,7 @@ def test_trajectories_bit_exact(golden_dir, preset):
         assert cov["bounce_balls"] > 0 and cov["robot_collision"] > 0
 
 
-@pytest.mark.parametrize("preset", ["T", "G", "D"])
+@pytest.mark.parametrize("preset", ["T", "G", "D", "X"])
 def test_thrust_entry_bit_exact(golden_dir, preset):
     """The continuous entry GameEnv.step(env, [(L, R), ...]) (RR_EnvBase.py:260-273) with Robot.set_thrust's
     int(round(x)) (RR_Robot.py:100-102), driven on the imported reference with the half-way cases +-0.5, +-1.5,
