@@ -83,7 +83,10 @@ typedef struct rr_config {
                                step) parks there; the call reports RR_STATUS_NOT_READY for it -- reward 0, done 0, its obs / obs_g
                                rows NOT written (reuse the buffers to keep the previous ones) -- and the next call resumes it where
                                it stopped, IGNORING the action it is given.  Each arena's trajectory as a function of the actions
-                               it accepted is bit-identical to step_budget_clocks = 0.  SimpleDuel3's own reward stack only. */
+                               it accepted is bit-identical to step_budget_clocks = 0.  Works with every reward program, observer, prior-step
+                               tracking and the goal-scoring mode: their side kernels take the on_step_begin copies when an arena's step
+                               BEGINS and run its on_step_end with the call that completes it (switch prior-step tracking on before the
+                               budget, or after a call without NOT_READY rows). */
     uint32_t reserved_;     /* 0                                                                       */
 } rr_config;
 

@@ -149,7 +149,7 @@ RR_HD void goal_step(typename C::Store *rec, int32_t *irec, const SimParams<type
     constexpr int NR = C::NR, NB = C::NB, BALLS = 10 * NR, ACC = 10 * NR + 8 * NB, I0 = 3 * NR; // irec: step episode ep_len ep_count last_len fault
     int st = *status;
     if (st & ST_WAS_RESET) { goal_state_clear<C>(gs); return; } // Goal.on_reset (RR_Goal.py:47-52)
-    if (st & ST_STEP_AFTER_DONE) return;
+    if (st & (ST_STEP_AFTER_DONE | ST_NOT_READY)) return; // (budgeted step: a step still in progress is no frame yet)
     const int frame = ++gs[0];
     R delta = (R)0;
     int alive = 0, dummy = 0;

@@ -246,6 +246,10 @@ __global__ void k_extras_begin(const typename C::Store *recs, int n, typename C:
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n || (mask && !mask[a])) return;
     Rec<C> q = { recs + (size_t)a * Arena<C>::P_STRIDE };
+    // budgeted step: an arena parked mid-step (bit 31 of the record's fzp word, step_arena) began its step in an earlier call -- the copies
+    // taken then are the ones its on_step_end will need (a masked reset re-seeds them: rr_reset clears the mark first)
+    const int32_t *irec = reinterpret_cast<const int32_t *>(q.p + Arena<C>::P_REALS);
+    if (!mask && irec[3 * C::NR + 6] < 0) return;
     extras_begin<C>(q, xs + (size_t)a * xs_stride<C>());
 }
 // After k_step, when a non-default keeper program and / or prior-step tracking is on: the program's rewards replace the
@@ -260,6 +264,7 @@ __global__ void k_extras_end(SimParams<typename C::Real> sp, typename C::Store *
     const int32_t st = status[a];
     typename C::Store *rec = recs + (size_t)a * Arena<C>::P_STRIDE;
     Rec<C> q = { rec };
+    if (st & ST_NOT_READY) return; // budgeted step: this arena's step is still in progress -- its on_step_end comes with the call that completes it
     if (st & ST_WAS_RESET) { extras_begin<C>(q, xs + (size_t)a * xs_stride<C>()); return; } // new episode: no prior step yet
     if (!rewrite || (st & ST_STEP_AFTER_DONE)) return; // nothing was stepped: the reward stays 0
     R rh, rg;
@@ -571,9 +576,6 @@ static int step_impl(rr_env *e, const int32_t *actions, const float *thrust, int
     DeviceGuard guard(e->cfg.device);
     hipStream_t s = (hipStream_t)stream;
     if ((e->custom_prog || e->track_prior || e->gs) && !status) status = e->status_buf; // the side kernels need the NaughtyBots / WAS_RESET bits
-    if (e->park && (e->custom_prog || e->track_prior || e->gs))
-        return fail(-1, "step budget: SimpleDuel3's own reward stack only (the side kernels of a custom reward program / prior-step "
-                        "tracking / goal scoring bracket whole steps)");
     int rc = dispatch(e, [&](auto c) {
         using CC = decltype(c); using RR = typename CC::Real;
         if constexpr (std::is_same<O, double>::value && !std::is_same<RR, double>::value) {
@@ -665,10 +667,6 @@ int rr_set_reward_program(rr_env *e, const int32_t *ids, int32_t n) {
     for (int i = 0; i < n; i++)
         if (ids[i] < KEEPER_NAUGHTY || ids[i] > KEEPER_PUSHNEG) return fail(-1, "rr_set_reward_program: unknown keeper id");
     DeviceGuard guard(e->cfg.device);
-    {
-        const bool custom = !(n == 3 && ids[0] == KEEPER_NAUGHTY && ids[1] == KEEPER_CHASE && ids[2] == KEEPER_PUSHPOS);
-        if (custom && e->park) return fail(-1, "rr_set_reward_program: a custom program cannot be combined with a step budget");
-    }
     e->prog.n = n;
     for (int i = 0; i < n; i++) e->prog.id[i] = ids[i];
     e->custom_prog = !(n == 3 && ids[0] == KEEPER_NAUGHTY && ids[1] == KEEPER_CHASE && ids[2] == KEEPER_PUSHPOS);
@@ -684,8 +682,6 @@ int rr_set_step_budget(rr_env *e, uint32_t clocks) {
     if (!e) return fail(-1, "rr_set_step_budget: null handle");
     if (clocks && e->cfg.dtype == RR_DTYPE_F32_STATE) // (a parked arena's record would be rounded to fp32 in the middle of its step)
         return fail(-1, "rr_set_step_budget: not with RR_DTYPE_F32_STATE");
-    if (clocks && (e->custom_prog || e->track_prior || e->gs))
-        return fail(-1, "rr_set_step_budget: SimpleDuel3's own reward stack only (no custom reward program / prior-step tracking / goal scoring)");
     DeviceGuard guard(e->cfg.device);
     if (clocks && !e->park) {
         size_t words = 0;

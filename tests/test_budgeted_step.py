@@ -122,3 +122,43 @@ def test_parked_step_is_dropped_by_a_state_rewrite_and_survives_nothing_else():
     ref = el.EmuEnv("T")
     ref.set_state(*state)
     assert _record(ref, ref.step(d["actions"][0])) == _record(env, r)
+
+
+@pytest.mark.parametrize("preset,goal", [("G", False), ("G", True), ("D", False), ("X", True)])
+def test_budgeted_equals_synchronous_with_another_keeper_program_and_goal_scoring(preset, goal):
+    """The other score keepers run as a program around the step (on_step_begin copies before it, the program after it:
+    rr_extras.hpp).  Under a budget the copies belong to the call in which the arena's step BEGAN and the program (and the goal
+    frame) to the call that completes it: a keeper stack that reads the prior-step copies (KeepMovingGuys) and one that ends in
+    NaughtyBots, with and without the goal-scoring mode, parked at every boundary / at random ones == synchronous."""
+    n = 30
+    robots, balls, actions = adv.make_states(preset, n, seed=5)
+    prog = [3, 2, 5, 4, 1]  # execution order: PushPos, Chase, KeepMoving, DontDrive, Naughty
+    parked = 0
+
+    def run(budget_mod, a, acts, seed=0):
+        env = el.EmuEnv(preset, time_limit=1, auto_reset=1)
+        env.set_poses(robots[a], balls[a])
+        env.set_program(prog)
+        if goal:
+            env.set_goal_scoring(True)
+        if budget_mod is None:
+            return [_record(env, env.step(x)) + (tuple(env.goal_scores()),) for x in acts], 0
+        env.park_seed(seed)
+        out, p = [], 0
+        for x in acts:
+            r = env.step_budget(x, budget_mod)
+            while r is None:
+                p += 1
+                r = env.step_budget((np.asarray(x) + 3) % 8, budget_mod)
+            out.append(_record(env, r) + (tuple(env.goal_scores()),))
+        return out, p
+
+    for a in range(n):
+        rng = np.random.RandomState(a)
+        acts = [actions[a] if rng.rand() < 0.6 else rng.randint(0, 8, actions[a].shape).astype(np.int32) for _ in range(4)]
+        ref, _ = run(None, a, acts)
+        for mod in (1, 3):
+            got, p = run(mod, a, acts, 31 * a + mod)
+            assert got == ref, (preset, goal, a, mod)
+            parked += p
+    assert parked > 10 * n
