@@ -111,6 +111,7 @@ def load_shape(counts, exact=False):
     or older than its sources -- hipcc has to be there for that; the same ABI, no fallback of any kind."""
     from . import build as _build
     key = (tuple(int(c) for c in counts), bool(exact))
+    _build.shape_lanes(*key[0])  # ValueError for counts the contact masks cannot hold: nothing to compile
     if key not in _shape_libs:
         path = _build.shape_lib_path(*key[0], exact=exact)
         if _build.shape_is_stale(*key[0], exact=exact) and (_build.sources_present() or not os.path.exists(path)):

@@ -2198,6 +2198,13 @@ RR_HDN int resolve_ball_collisions(Arena<C> &A, const SimParams<typename C::Real
             RR_SYNC();
         }
         RR_STAMP(17);
+#if !RR_GPU && defined(RR_EMU_TRACE)
+        if (RR_EMU_TRACE > 1) { // host emulation, trace level 2: the balls after this pass, bit for bit (pass-periodicity studies, profiles/r04/pass_replay_experiment)
+            fprintf(stderr, "E pass %d state", count);
+            for (int b = 0; b < C::NB; b++) fprintf(stderr, " %a %a %a %a %a %a %a %a", (double)A.p.bcx[b], (double)A.p.bcy[b], (double)A.p.bl[b], (double)A.p.brt[b], (double)A.p.bt[b], (double)A.p.bb[b], (double)A.p.bvx[b], (double)A.p.bvy[b]);
+            fprintf(stderr, "\n");
+        }
+#endif
     }
     RR_TRACE("E resolve done in %d passes\n", count);
     return 1;
@@ -2585,6 +2592,30 @@ RR_HD bool substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     }
     prev_moved = bots_moved;
     return false;
+}
+// Balls OUTSIDE a would-be island K that belong to the picture K reproduces: at rest (v = 0), not touched in the compared sub-steps
+// (not in the hit set), bit for bit what they were a sub-step earlier, and within the broad-phase bound of one of K's robots.  Such
+// a ball -- typically one the robot pushed aside earlier, resting half a pixel off its flank -- fires the frozen variant's ball-robot
+// bound in EVERY sub-step and thaws the island on the spot, only to be found untouched again: freeze, thaw, twelve expensive sub-steps
+// per step for as long as it lies there (the slowest arena of a random-policy launch at the steady state: ~1 ms against a median
+// wavefront of 65 us, profiles/r04/verify/).  It joins the island instead.  Exact for the same reason the island is: K + the ball was
+// identical at two consecutive frame begins and nothing outside hit either, so the sub-step maps K + the ball onto itself again as
+// long as nothing outside comes near -- which the frozen variant's bounds keep checking, now around the ball too.
+template <class C> RR_HD uint32_t resting_neighbours(const Arena<C> &A, const Hit &k, uint32_t chg_b) {
+    using R = typename C::Real;
+    uint64_t m = 0;
+    RR_FOR_LANES(l) {
+        bool near = false;
+        const int b = l < C::NB ? l : 0;
+        if (l < C::NB && !((k.b >> b) & 1u) && !((chg_b >> b) & 1u) && A.p.bvx[b] == (R)0 && A.p.bvy[b] == (R)0 && ball_in_play(A, b)) {
+            for (int r = 0; r < C::NR; r++) {
+                const R dx = A.p.bcx[b] - A.p.rcx[r], dy = A.p.bcy[b] - A.p.rcy[r];
+                near = near | ((((k.r >> r) & 1u) != 0) & (dx * dx + dy * dy <= (R)(36.0 * 36.0)));
+            }
+        }
+        RR_VOTE(m, l, near);
+    }
+    return (uint32_t)m & ((1u << C::NB) - 1u);
 }
 // after the last sub-step: the pose-ring bookkeeping the next sub-step would have done
 template <class C> RR_HD void substeps_end(Arena<C> &A, uint32_t prev_moved) {
@@ -3334,8 +3365,18 @@ RR_HD void step_arena(Arena<C> &A, const SimParams<typename C::Real> &sp, uint64
                 // (a one-robot arena too: robot + ball squeezed against a wall is a whole-arena fixed point EXCEPT for those
                 // drifting edge bits, which is most of what a trained or chase policy runs into on preset T)
                 if (island_ok) {
-                    RR_TRACE("E freeze robots %x balls %x after sub-step %d\n", hit.r, hit.b, f);
                     fz = hit;
+#ifndef RR_NO_NEIGHBOURS // (A/B builds only)
+                    if (hit.r) {
+                        const uint32_t nb_ = resting_neighbours(A, hit, chg_b);
+#if RR_CARRY
+                        if (nb_ && !(carry_deps<C>(hit.b | nb_) & chg_b)) fz.b |= nb_;
+#else
+                        fz.b |= nb_;
+#endif
+                    }
+#endif
+                    RR_TRACE("E freeze robots %x balls %x (hit %x) after sub-step %d\n", fz.r, fz.b, hit.b, f);
                     fz_bits = fz_pack_bits(n_sub, st_sub);
                 } else {
                     RR_TRACE("E no freeze: island changed r %x b %x, moved %x, clamped %d\n", chg_r & hit.r, chg_b & hit.b, (prev_moved | snap_moved) & hit.r, (int)robots_clamped(A, hit.r));

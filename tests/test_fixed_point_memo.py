@@ -194,3 +194,28 @@ def test_freeze_carried_across_steps_is_exact_on_stuck_arenas_of_a_chase_rollout
         for k in fired:
             fired[k] += c[k]
     assert fired["step begins frozen"] >= (150 if preset == "T" else 5) and fired["freeze"] >= (40 if preset == "T" else 5), fired
+
+
+def test_resting_neighbours_join_the_island_on_slow_random_policy_arenas():
+    """tests/data/stuck_random_G.npz: the busiest arena of the slowest wavefront of 40 consecutive random-policy launches at the steady
+    state (MI355X, round 4).  Several of them are a robot squeezing a ball against a wall with a SECOND ball resting half a pixel off
+    its flank: that ball fired the frozen variant's ball-robot bound in every sub-step -- freeze, thaw, twelve expensive sub-steps
+    per step.  A ball at rest, untouched and unchanged, within the bound of an island robot now joins the island (rr_sim.hpp:
+    resting_neighbours).  Shortcuts on == off bit for bit over six steps (actions kept, then changed), and the ping-pong is gone."""
+    d = np.load(os.path.join(HERE, "data", "stuck_random_G.npz"))
+    n = len(d["step"])
+    ev = {"E freeze": 0, "thaw in phase": 0, "resolve gave up": 0}
+    joined = 0
+    for a in range(n):
+        rng = np.random.RandomState(7 + a)
+        state = (d["robots"][a], d["robots_i"][a], d["balls"][a], int(d["step"][a]))
+        acts = [d["actions"][a]] * 3 + [rng.randint(0, 8, d["actions"][a].shape).astype(np.int32) for _ in range(3)]
+        on = _rollout_seq("G", state, acts, True)
+        off = _rollout_seq("G", state, acts, False)
+        assert on == off, a
+        if d["work"][a] > 150:  # the ~1 ms arenas
+            c = _count_events(lambda: _rollout_seq("G", state, acts[:3], True), tuple(ev) + ("(hit",))
+            for k in ev:
+                ev[k] += c[k]
+    # (with every shortcut but this one the three monsters of the fixture gave up 11-12 resolve loops per step: > 130 in 4 x 3 steps)
+    assert ev["E freeze"] >= 4 and ev["resolve gave up"] < 80, ev

@@ -263,9 +263,21 @@ def test_abi_rejects_misuse_without_crashing():
         env.step(torch.zeros(8, 2, dtype=torch.int32, device="cuda"))
     with pytest.raises(RRError, match="bad team/robot/ball index"):
         env.get_game_state(int_team=1, robot_idx=3)
+    import ctypes as C
     import dataclasses
+    from roborugby_amd import _lib
+    # entity counts the contact masks cannot hold are refused before anything is compiled (other counts outside the built shapes get a
+    # one-shape library on demand: tests/test_custom_shape.py) ...
+    with pytest.raises(ValueError, match="contact masks"):
+        rr.BatchedRoboRugbyEnv(8, preset=dataclasses.replace(rr.PRESETS["G"], nr_happy=5, nr_grumpy=4))
+    # ... and the main library itself refuses counts it was not built for
+    p = rr.PRESETS["T"]
+    cfg = _lib.RRConfig(struct_size=C.sizeof(_lib.RRConfig), num_envs=8, nr_happy=1, nr_grumpy=0, nb_pos=2, nb_neg=0, arena_w=p.arena_w,
+                        arena_h=p.arena_h, game_len_steps=p.game_len_steps, game_mode=0, time_limit=1, auto_reset=1, reset_on_fault=1,
+                        dtype=0, device=0, seed=1, arena_offset=0, step_budget_clocks=0, reserved_=0)
+    h = C.c_void_p()
     with pytest.raises(RRError, match="unsupported entity counts"):
-        rr.BatchedRoboRugbyEnv(8, preset=dataclasses.replace(rr.PRESETS["T"], nb_pos=2))
+        _lib.check(_lib.load().rr_create(C.byref(cfg), C.byref(h)), "rr_create", _lib.load())
     with pytest.raises(RRError, match="num_envs must be positive"):
         rr.BatchedRoboRugbyEnv(0, preset="T")
     # bad actions are a per-arena status, not an error: the arena keeps its previous thrust (KeyError in the reference)
