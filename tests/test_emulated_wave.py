@@ -17,7 +17,7 @@ def _diff(st, ref_r, ref_b):
 
 
 @pytest.mark.parametrize("preset,stride,narrow", [("T", 3, False), ("G", 4, False), ("T", 4, True), ("G", 5, True), ("D", 3, False), ("D", 4, True),
-                                                       ("X", 3, False), ("X", 3, True)])
+                                                       ("X", 5, False), ("X", 6, True)])
 def test_emulated_kernel_vs_reference_golden(golden_dir, preset, stride, narrow):
     """narrow=True runs the phases with VW = 4 (T) / 16 (G) lanes per arena, i.e. in several rounds -- the
     lane->task maps of the packed GPU builds (several arenas per wavefront)."""
