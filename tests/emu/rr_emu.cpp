@@ -98,6 +98,10 @@ typedef Cfg<1, 1, 1, 1, double, 4> CD64n;
 // compiles on demand (roborugby_amd/build.py); one lane per entity needs 8 lanes
 typedef Cfg<2, 1, 2, 3, double, 64> CX64;
 typedef Cfg<2, 1, 2, 3, double, 8> CX64n;
+// ... and one that packs at FOUR lanes per arena (1 + 1 robots, 2 + 1 balls): the narrow phases' "fewer than eight lanes" variants with
+// more than one ball, a combination none of the built shapes has
+typedef Cfg<1, 1, 2, 1, double, 64> CY64;
+typedef Cfg<1, 1, 2, 1, double, 4> CY64n;
 
 struct Handle { int kind; void *p; };
 
@@ -114,6 +118,8 @@ struct Handle { int kind; void *p; };
     case 8: { auto *e = (Emu<CD64n> *)(h)->p; typedef CD64n CC; __VA_ARGS__; } break; \
     case 9: { auto *e = (Emu<CX64> *)(h)->p; typedef CX64 CC; __VA_ARGS__; } break; \
     case 10: { auto *e = (Emu<CX64n> *)(h)->p; typedef CX64n CC; __VA_ARGS__; } break; \
+    case 11: { auto *e = (Emu<CY64> *)(h)->p; typedef CY64 CC; __VA_ARGS__; } break; \
+    case 12: { auto *e = (Emu<CY64n> *)(h)->p; typedef CY64n CC; __VA_ARGS__; } break; \
     }
 
 extern "C" {
@@ -132,8 +138,10 @@ void emu_sincos(double x, double *s, double *c) { m_sincos(x, *s, *c); }
 Handle *emu_create(int preset, int f32, double W, double H, int game_len, int game_mode, int time_limit, int auto_reset,
                    uint64_t seed) {
     Handle *h = new Handle;
-    h->kind = preset == 3 ? (f32 == 2 ? 10 : 9) : preset == 2 ? 6 + f32 : preset + 2 * f32; // preset 3 = X (fp64 only)
+    h->kind = preset == 4 ? (f32 == 2 ? 12 : 11) : preset == 3 ? (f32 == 2 ? 10 : 9) : preset == 2 ? 6 + f32 : preset + 2 * f32; // presets 3, 4 = X, Y (fp64 only)
     switch (h->kind) {
+    case 11: h->p = calloc(1, sizeof(Emu<CY64>)); break;
+    case 12: h->p = calloc(1, sizeof(Emu<CY64n>)); break;
     case 9: h->p = calloc(1, sizeof(Emu<CX64>)); break;
     case 10: h->p = calloc(1, sizeof(Emu<CX64n>)); break;
     case 6: h->p = calloc(1, sizeof(Emu<CD64>)); break;

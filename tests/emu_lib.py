@@ -87,7 +87,7 @@ class EmuEnv:
         self.nr = cfg["nr_h"] + cfg["nr_g"]
         self.nb = cfg["nb_p"] + cfg["nb_n"]
         # narrow=True: fp64 with VW = 4 (T, D) / 16 (G) lanes per arena, i.e. multi-round phases as in the packed builds
-        self.h = lib(self._exact).emu_create({"T": 0, "G": 1, "D": 2, "X": 3}[preset], 2 if narrow else int(f32), cfg["W"], cfg["H"], cfg["game_len"],
+        self.h = lib(self._exact).emu_create({"T": 0, "G": 1, "D": 2, "X": 3, "Y": 4}[preset], 2 if narrow else int(f32), cfg["W"], cfg["H"], cfg["game_len"],
                                   cfg["game_mode"], time_limit, int(auto_reset) | (int(reset_on_fault) << 1), seed)
 
     def __del__(self):

@@ -18,6 +18,7 @@ PRESETS = {  # RR_Constants.py:6-7,24-25,30-34
     "D": dict(nr_h=1, nr_g=1, nb_p=1, nb_n=1, W=800.0, H=800.0, game_len=4500, game_mode=1),  # the duel: G's constants, one entity each
     # a shape outside the library's built list (compiled on demand: roborugby_amd.build.build_shape_library): odd counts, unequal teams
     "X": dict(nr_h=2, nr_g=1, nb_p=2, nb_n=3, W=800.0, H=800.0, game_len=4500, game_mode=1),
+    "Y": dict(nr_h=1, nr_g=1, nb_p=2, nb_n=1, W=800.0, H=800.0, game_len=4500, game_mode=1),  # four lanes per arena, three balls (emulation vs oracle only)
 }
 
 

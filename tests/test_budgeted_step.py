@@ -55,7 +55,8 @@ def _scrub():
     el.lib().emu_debug_scrub(0)
 
 
-@pytest.mark.parametrize("preset,n,narrow", [("T", 120, False), ("T", 60, True), ("G", 40, False), ("G", 30, True), ("D", 60, False), ("D", 40, True)])
+@pytest.mark.parametrize("preset,n,narrow", [("T", 120, False), ("T", 60, True), ("G", 40, False), ("G", 30, True), ("D", 60, False), ("D", 40, True),
+                                                  ("X", 30, True), ("Y", 40, True)])
 def test_budgeted_equals_synchronous_on_contact_dense_states(preset, n, narrow):
     robots, balls, actions = adv.make_states(preset, n, seed=11 + int(narrow))
     parked = 0

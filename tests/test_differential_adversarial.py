@@ -44,7 +44,7 @@ def _compare(preset, res, st, r_res, r_st, ctx, inputs=None):
 
 
 @pytest.mark.parametrize("preset,n,narrow", [("T", 360, False), ("T", 240, True), ("G", 150, False), ("G", 150, True), ("D", 240, False), ("D", 180, True),
-                                                  ("X", 200, False), ("X", 200, True)])
+                                                  ("X", 200, False), ("X", 200, True), ("Y", 240, False), ("Y", 240, True)])
 def test_emulated_kernel_vs_oracle_on_adversarial_states(preset, n, narrow):
     robots, balls, actions = adv.make_states(preset, n, seed=11 + int(narrow))
     env = el.EmuEnv(preset, narrow=narrow)
@@ -66,7 +66,7 @@ def test_emulated_kernel_vs_oracle_on_adversarial_states(preset, n, narrow):
 
 
 @pytest.mark.parametrize("preset,n,narrow", [("T", 900, False), ("T", 600, True), ("G", 160, False), ("G", 120, True), ("D", 400, False), ("D", 300, True),
-                                                  ("X", 240, False), ("X", 200, True)])
+                                                  ("X", 240, False), ("X", 200, True), ("Y", 300, True)])
 def test_emulated_kernel_vs_oracle_on_balls_around_robot_corners(preset, n, narrow):
     """the broad phase's corner-zone bound (ball_near_robot) must not drop a hit: balls at 6.4-7.7 px from robot corners"""
     robots, balls, actions = adv.make_corner_states(preset, n, seed=3 + int(narrow))

@@ -64,7 +64,7 @@ def _count_fixed_points(fn):
     return _count_events(fn)["fixed point"]
 
 
-@pytest.mark.parametrize("preset,n,narrow", [("T", 240, False), ("T", 120, True), ("G", 60, False), ("G", 60, True)])
+@pytest.mark.parametrize("preset,n,narrow", [("T", 240, False), ("T", 120, True), ("G", 60, False), ("G", 60, True), ("X", 60, True), ("Y", 80, True)])
 def test_shortcut_is_bit_exact_on_contact_dense_rollouts(preset, n, narrow):
     robots, balls, actions = adv.make_states(preset, n, seed=5 + int(narrow))
     for a in range(n):
