@@ -180,12 +180,15 @@ def test_step_can_be_captured_into_a_hip_graph():
 
 
 @BUILDS
-@pytest.mark.parametrize("preset", ["T", "G"])
+@pytest.mark.parametrize("preset", ["T", "G", "Grandom"])
 def test_islands_carried_across_steps_shortcuts_off_equals_on(preset, exact):
     """Stuck arenas from the slowest wavefronts of a chase-policy rollout (tests/data/stuck_chase_*.npz): ten steps in which
     every robot keeps its action most of the time (the frozen island is carried into the next step), changes it now and then
     (recomputed), with one rr_set_state of the state they have in between (nothing may be carried) -- shortcuts on == off."""
-    d = np.load(os.path.join(HERE, "data", f"stuck_chase_{preset}.npz"))
+    # ("Grandom": the slowest arenas of RANDOM-policy launches at the steady state, tests/data/stuck_random_G.npz -- among them the ones
+    # whose island gains a resting neighbour ball, rr_sim.hpp: resting_neighbours)
+    d = np.load(os.path.join(HERE, "data", "stuck_random_G.npz" if preset == "Grandom" else f"stuck_chase_{preset}.npz"))
+    preset = preset[0]
     n = len(d["step"])
     rng = np.random.RandomState(5)
     acts = []
