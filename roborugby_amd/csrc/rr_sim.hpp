@@ -108,6 +108,13 @@ __device__ unsigned long long g_rr_wave_t[2 * 65536]; // [start, end] s_memtime 
 #define RR_TRACE(...) do { } while (0)
 #endif
 
+// The frozen island's "witness" tests (substep): default build only -- in the parity build every extra detection sweep would walk the
+// reference's scratch rect.  -DRR_NO_WITNESS: A/B builds.
+#if defined(RR_NO_WITNESS)
+#define RR_WITNESS 0
+#else
+#define RR_WITNESS (!RR_CARRY)
+#endif
 // rare branches (contact paths, reset, frozen islands): tells the register allocator where spilling is cheap
 #define RR_UNLIKELY(x) __builtin_expect(!!(x), 0)
 
@@ -2266,7 +2273,7 @@ RR_HDN void undo_naughty_movement(Arena<C> &A, const SimParams<typename C::Real>
 // the two fast phases of a sub-step (see substep); FZ: an island is frozen
 template <class C, bool FZ>
 RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, const Hit &fz, uint32_t prev_moved, uint64_t &m_rr,
-                          uint64_t &m_br, uint64_t &m_wm) {
+                          uint64_t &m_br, uint64_t &m_wm, uint64_t &m_brk) {
     using R = typename C::Real;
     // A robot's move is spread over a PAIR of lanes (2r, 2r+1) when the virtual wave has them: both lanes run the same
     // instructions on different data -- two of the three sin/cos evaluations at once, then one renormalised corner each --
@@ -2277,7 +2284,7 @@ RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, co
     RR_LANE_VAR(MovePlan<R>, mp);           // the robot's move plan (both lanes of the pair hold a copy)
     RR_LANE_VAR(R, s3v); RR_LANE_VAR(R, c3v); // sin / cos of the third angle (the re-centring after a pivot), issued with the corners
     RR_FOR_LANES(l) {
-        bool c_rr = false, c_br = false;
+        bool c_rr = false, c_br = false, c_brk = false; // (c_brk, frozen variant: an outside ball within the bound of an ISLAND robot -- see "witness" in substep)
         const int r = PAIRED ? (l >> 1) : l, part = PAIRED ? (l & 1) : 0;
         // a frozen robot still makes its move here (and is put back at the end of the sub-step): how the move meets the walls
         // depends on the robot's incrementally kept edges, so it is re-evaluated, not assumed; only its pair tests are skipped
@@ -2331,7 +2338,8 @@ RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, co
                         const R ux = (q[2] - q[0]) * (R)0.05, uy = (q[3] - q[1]) * (R)0.05, vx = (q[4] - q[0]) * (R)0.025, vy = (q[5] - q[1]) * (R)0.025;
                         cl = (m_abs(dx * ux + dy * uy) <= (R)20.05) & (m_abs(dx * vx + dy * vy) <= (R)30.05);
                     }
-                    c_br = c_br | cl;
+                    if (FZ && ((fz.r >> r2) & 1u)) c_brk = c_brk | cl;
+                    else c_br = c_br | cl;
                 }
             } else { // frozen ball: anywhere within its recorded excursion, against the robots outside the island
                 const R reach = (R)36.05 + A.exc[l];
@@ -2343,6 +2351,7 @@ RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, co
         }
         RR_VOTE(m_rr, l, c_rr);
         RR_VOTE(m_br, l, c_br);
+        if (FZ) RR_VOTE(m_brk, l, c_brk);
     }
     if (PAIRED) {
         // (the broad phase above read robot centres that no lane has moved yet: its bounds hold a fortiori)
@@ -2382,10 +2391,10 @@ RR_HD void substep_phase1(Arena<C> &A, const SimParams<typename C::Real> &sp, co
     }
 }
 template <class C, bool FZ>
-RR_HD void substep_phase2(Arena<C> &A, const SimParams<typename C::Real> &sp, const Hit &fz, uint64_t &m_any, int icm) {
+RR_HD void substep_phase2(Arena<C> &A, const SimParams<typename C::Real> &sp, const Hit &fz, uint64_t &m_any, int icm, uint64_t &m_anyk) {
     using R = typename C::Real;
     RR_FOR_LANES(l) {
-        bool c = false;
+        bool c = false, ck = false; // (ck, frozen variant: a rolled ball within the radius bound of an ISLAND robot)
         if (l < C::NB && !(FZ && ((fz.b >> l) & 1u))) {
             ball_move_lane(A, l);
             const R mx = A.p.bcx[l], my = A.p.bcy[l];
@@ -2403,7 +2412,7 @@ RR_HD void substep_phase2(Arena<C> &A, const SimParams<typename C::Real> &sp, co
             for (int r = 0; r < C::NR; r++) {
                 if (FZ && ((fz.r >> r) & 1u)) { // a frozen robot: its frame-begin or its (undone) moved pose -- the radius bound + 3 px
                     R dx = mx - A.p.rcx[r], dy = my - A.p.rcy[r];
-                    c = c | (dx * dx + dy * dy <= (R)(36.0 * 36.0));
+                    ck = ck | (dx * dx + dy * dy <= (R)(36.0 * 36.0));
                 } else {
                     c = c | ball_near_robot(A, l, r);
                 }
@@ -2411,6 +2420,7 @@ RR_HD void substep_phase2(Arena<C> &A, const SimParams<typename C::Real> &sp, co
             c = c | (ball_in_play(A, l) & ball_collided_wall(A, sp, l));
         }
         RR_VOTE(m_any, l, c);
+        if (FZ) RR_VOTE(m_anyk, l, ck);
     }
 }
 // _push_balls over a frozen hit list (RR_EnvBase.py:335-339), ball-major order
@@ -2493,7 +2503,7 @@ RR_HD bool substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     RR_T0();
     uint64_t m_any = 0;
     int count0 = 0;
-    bool reentry = false;
+    bool reentry = false, put_back = false;
     if constexpr (BUDGET) reentry = mid->phase == 1;
     if (RR_UNLIKELY(reentry)) {
         bots_moved = mid->bots_moved; balls_moved = mid->balls_moved; naughty = mid->n_sub; st = mid->st_sub; work = mid->work; hit = mid->hit;
@@ -2504,16 +2514,35 @@ RR_HD bool substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     // phase 1: frame hooks, robot moves AND the exact broad phase.  The broad phase runs in the same phase as the moves:
     // it may see a robot centre from before or after this sub-step's move, so its bounds carry the largest centre
     // displacement a move can cause (1 px drive / 0.17 px pivot / <= 1.5 px wall clamp: 3 px per robot is generous).
-    uint64_t m_rr = 0, m_br = 0, m_wm = 0;
+    uint64_t m_rr = 0, m_br = 0, m_wm = 0, m_brk = 0;
     const bool frozen = (fz.r | fz.b) != 0; // the frozen variants are separate instantiations: the common path pays nothing
-    if (RR_UNLIKELY(frozen)) substep_phase1<C, true>(A, sp, fz, prev_moved, m_rr, m_br, m_wm);
-    else substep_phase1<C, false>(A, sp, fz, prev_moved, m_rr, m_br, m_wm);
+    if (RR_UNLIKELY(frozen)) substep_phase1<C, true>(A, sp, fz, prev_moved, m_rr, m_br, m_wm, m_brk);
+    else substep_phase1<C, false>(A, sp, fz, prev_moved, m_rr, m_br, m_wm, m_brk);
     RR_SYNC();
     RR_STAMP(1);
-    if (RR_UNLIKELY((fz.r | fz.b) && (m_rr | m_br | m_wm))) { // thaw before anything depended on the island
-        RR_TRACE("E thaw in phase 1: rr %llx br %llx wm %llx\n", (unsigned long long)m_rr, (unsigned long long)m_br, (unsigned long long)m_wm);
-        thaw_island(A, sp, fz, bots_moved);
-        m_rr = 1; m_br = 1;
+    // Witness (default build).  A ball OUTSIDE the island within the bounds of one of its robots -- drifting past its flank, half a
+    // pixel away -- used to thaw the island in every sub-step only to be found untouched: twelve expensive sub-steps per step while it
+    // lasts.  The island K reproduces itself as long as nothing outside touches it, and the only tests the reference runs on such a
+    // pair (ball x, island robot r) in a sub-step are ball_robot_collided at: (x before its roll, r moved) in the push sweep; (x rolled,
+    // r moved) in every resolve pass and the first undo iteration; (x rolled, r put back) in the later undo iterations.  If those three
+    // narrow tests are negative the pair did not interact and K stays frozen: exact.  They run here at exactly those poses -- the frozen
+    // robots have made their real move in phase 1, are put back below with the reference's own undo arithmetic, and are restored bit for
+    // bit if the third test fires (then the sub-step takes the thaw-after-the-roll path as before).
+    uint32_t kx = 0; // pairs (ball outside the island, robot inside)
+    if (RR_WITNESS && RR_UNLIKELY(frozen))
+        for (int b = 0; b < C::NB; b++) if (!((fz.b >> b) & 1u)) kx |= fz.r << (b * C::NR);
+    if (!RR_WITNESS) m_br |= m_brk;
+    if (RR_UNLIKELY((fz.r | fz.b) && (m_rr | m_br | m_wm | m_brk))) { // thaw before anything depended on the island
+        bool thaw = true;
+        if (RR_WITNESS && !(m_rr | m_br | m_wm)) { // only (outside ball, island robot) bounds fired: the push sweep's test decides
+            thaw = (detect_ball_robot<C, false>(A, sp) & kx) != 0u;
+            RR_TRACE("E witness 1 (before the roll, robots moved): %s\n", thaw ? "hit" : "clear");
+        }
+        if (thaw) {
+            RR_TRACE("E thaw in phase 1: rr %llx br %llx wm %llx\n", (unsigned long long)m_rr, (unsigned long long)(m_br | m_brk), (unsigned long long)m_wm);
+            thaw_island(A, sp, fz, bots_moved);
+            m_rr = 1; m_br = 1;
+        }
     }
     if (RR_UNLIKELY(m_rr)) {
         // an undone robot changes the ball-robot picture: let the full detection decide.  (No pair really touching -- most
@@ -2541,10 +2570,45 @@ RR_HD bool substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
     // runs in the same phase as the roll, so the other ball may be seen before or after its own roll: the bound (A.reach,
     // written at the frame hooks and refreshed by the push) adds the most it can travel in its roll.  Ball-robot uses the settled robot centres; the wall test is the exact int-rect test.
     RR_TRACE("E phase1 rr %d br %d\n", (int)(m_rr != 0), (int)(m_br != 0));
-    if (RR_UNLIKELY(frozen && (fz.r | fz.b))) substep_phase2<C, true>(A, sp, fz, m_any, icm);
-    else substep_phase2<C, false>(A, sp, fz, m_any, icm);
+    uint64_t m_anyk = 0;
+    if (RR_UNLIKELY(frozen && (fz.r | fz.b))) substep_phase2<C, true>(A, sp, fz, m_any, icm, m_anyk);
+    else substep_phase2<C, false>(A, sp, fz, m_any, icm, m_anyk);
     RR_SYNC();
     RR_STAMP(4);
+    if (!RR_WITNESS) m_any |= m_anyk;
+    if (RR_WITNESS && RR_UNLIKELY((fz.r | fz.b) && !m_any && m_anyk)) { // witnesses 2 and 3 (see above)
+        bool hitw = (detect_ball_robot<C, false>(A, sp) & kx) != 0u;
+        RR_TRACE("E witness 2 (after the roll, robots moved): %s\n", hitw ? "hit" : "clear");
+        if (!hitw) {
+            // the island's robots are put back as the undo loop of their (reproduced) sub-step does -- a lane keeps what it needs to
+            // restore its robot bit for bit: centre, edges, rotation (the corner offsets are a function of the rotation)
+            RR_LANE_VAR(R, w0); RR_LANE_VAR(R, w1); RR_LANE_VAR(R, w2); RR_LANE_VAR(R, w3); RR_LANE_VAR(R, w4); RR_LANE_VAR(R, w5); RR_LANE_VAR(R, w6);
+            RR_FOR_LANES(l) {
+                const int r = l < C::NR ? l : 0;
+                RR_LV(w0, l) = A.p.rcx[r]; RR_LV(w1, l) = A.p.rcy[r]; RR_LV(w2, l) = A.p.rl[r]; RR_LV(w3, l) = A.p.rrt[r];
+                RR_LV(w4, l) = A.p.rt[r]; RR_LV(w5, l) = A.p.rb[r]; RR_LV(w6, l) = A.p.rrot[r];
+            }
+            RR_FOR_LANES(l) { if (l < C::NR && ((fz.r >> l) & 1u)) robot_undo_lane(A, sp, l); }
+            RR_SYNC();
+            hitw = (detect_ball_robot<C, false>(A, sp) & kx) != 0u;
+            RR_TRACE("E witness 3 (after the roll, robots put back): %s\n", hitw ? "hit" : "clear");
+            if (hitw) { // the reference's undo loop would have found this contact: back to the moved poses, then the full path
+                RR_FOR_LANES(l) {
+                    if (l < C::NR && ((fz.r >> l) & 1u)) {
+                        if (A.p.rrot[l] != RR_LV(w6, l)) corners_for<R>(RR_LV(w6, l), (R)10, (R)20, sp.rob_cdist, RR_REL(A)[l]);
+                        A.p.rcx[l] = RR_LV(w0, l); A.p.rcy[l] = RR_LV(w1, l); A.p.rl[l] = RR_LV(w2, l); A.p.rrt[l] = RR_LV(w3, l);
+                        A.p.rt[l] = RR_LV(w4, l); A.p.rb[l] = RR_LV(w5, l); A.p.rrot[l] = RR_LV(w6, l);
+                        A.i.mc[l] += 1;
+                        A.sides_ok = 0;
+                    }
+                }
+                RR_SYNC();
+            } else {
+                put_back = true; // (the end of the sub-step has nothing left to do for the island)
+            }
+        }
+        if (hitw) m_any = 1;
+    }
     if (RR_UNLIKELY((fz.r | fz.b) && m_any)) { // thaw after the roll phase: the island catches up (move, push, roll), then the full path
         RR_TRACE("E thaw in phase 2\n");
         const Hit k = fz;
@@ -2584,7 +2648,7 @@ RR_HD bool substep(Arena<C> &A, const SimParams<typename C::Real> &sp, uint32_t 
         if (rr_ok_ == 0) { work += 8; undo_naughty_movement(A, sp, balls_moved, bots_moved, st, hit); }
     }
     RR_STAMP(6);
-    if (RR_UNLIKELY(fz.r)) { // still frozen: the island's robots made their move in phase 1; the undo they would have met puts them back
+    if (RR_UNLIKELY(fz.r) && !put_back) { // still frozen: the island's robots made their move in phase 1; the undo they would have met puts them back
         RR_FOR_LANES(l) {
             if (l < C::NR && ((fz.r >> l) & 1u)) robot_undo_lane(A, sp, l);
         }
