@@ -15,7 +15,7 @@ def _close(a, b, tol=TOL):
     return np.array_equal(np.isnan(a), np.isnan(b)) and (np.nan_to_num(np.abs(a - b)).max() if a.size else 0.0) < tol
 
 
-@pytest.mark.parametrize("preset", ["T", "G", "D"])
+@pytest.mark.parametrize("preset", ["T", "G", "D", "X"])
 def test_emulated_side_kernels_vs_reference_golden(golden_dir, preset):
     t = np.load(f"{golden_dir}/mix_{preset}.npz")
     meta = json.loads(str(t["meta"]))
@@ -56,7 +56,7 @@ def test_keeper_exec_order_rule():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("preset", ["T", "G", "D"])
+@pytest.mark.parametrize("preset", ["T", "G", "D", "X"])
 def test_gpu_mixin_stacks_vs_reference_golden(golden_dir, preset):
     import torch
     import roborugby_amd as rr

@@ -16,7 +16,7 @@ def _eq(a, b):
     return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
 
 
-@pytest.mark.parametrize("preset", ["T", "G", "D"])
+@pytest.mark.parametrize("preset", ["T", "G", "D", "X"])
 def test_mixin_rewards_and_observers_bit_exact(golden_dir, preset):
     t = np.load(f"{golden_dir}/mix_{preset}.npz")
     meta = json.loads(str(t["meta"]))
