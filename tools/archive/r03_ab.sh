@@ -1,5 +1,5 @@
 #!/bin/bash
-# generic A/B of variant libraries with 200-step lines: tools/r03_ab.sh <tag> "<bench args>;<bench args>;..." lib1 lib2 ...
+# generic A/B of variant libraries with 200-step lines: tools/archive/r03_ab.sh <tag> "<bench args>;<bench args>;..." lib1 lib2 ...
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT; TAG=$1; ARGSETS=$2; shift 2
 mkdir -p gpurun_out/$TAG

@@ -1,6 +1,6 @@
 #!/bin/bash
 # r03: the budgeted step -- targeted GPU tests, then chase-policy bench lines at several budgets next to the synchronous ones.
-# usage: tools/r03_budget.sh <tag> ["pytest -k expr"]
+# usage: tools/archive/r03_budget.sh <tag> ["pytest -k expr"]
 TAG=${1:-r03_budget}; KEXPR=${2:-budget or thrust_entry or bench_gpus_2 or gloo_ranks}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of fused-DQN builds: tools/r03_dqn_ab.sh <tag> lib1 lib2 ...  (update / act timing of each, then the gradient tests with the LAST one)
+# A/B of fused-DQN builds: tools/archive/r03_dqn_ab.sh <tag> lib1 lib2 ...  (update / act timing of each, then the gradient tests with the LAST one)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT; TAG=$1; shift
 mkdir -p gpurun_out/$TAG

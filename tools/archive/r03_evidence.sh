@@ -6,9 +6,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
-bash tools/r03_profile.sh ${TAG}_G > $OUT/prof_G.txt 2>&1 || { echo "profile G failed"; tail -5 $OUT/prof_G.txt; exit 1; }
+bash tools/archive/r03_profile.sh ${TAG}_G > $OUT/prof_G.txt 2>&1 || { echo "profile G failed"; tail -5 $OUT/prof_G.txt; exit 1; }
 echo "profile G done"
-bash tools/r03_profile.sh ${TAG}_T --preset T > $OUT/prof_T.txt 2>&1 || { echo "profile T failed"; tail -5 $OUT/prof_T.txt; exit 1; }
+bash tools/archive/r03_profile.sh ${TAG}_T --preset T > $OUT/prof_T.txt 2>&1 || { echo "profile T failed"; tail -5 $OUT/prof_T.txt; exit 1; }
 echo "profile T done"
 bash tools/pmc_sq2.sh ${TAG}_G --no-stagger > $OUT/sq_G.txt 2>&1 || { echo "sq G failed"; exit 1; }
 tail -25 $OUT/sq_G.txt

@@ -2,7 +2,7 @@
 # r03 rocprofv3 evidence for bench.py's default (driver) command: kernel trace + stats, then FETCH_SIZE / WRITE_SIZE in two separate
 # --pmc passes.  bench.py pre-rolls one whole episode outside its timed region (arenas at random episode phases), so the trace holds
 # thousands of k_step launches: tools/summarize_profile.py reports the LAST K of them (the timed region) next to the all-launch stats.
-# usage: tools/r03_profile.sh <tag> [bench args...]
+# usage: tools/archive/r03_profile.sh <tag> [bench args...]
 set -e
 TAG=${1:-r03}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
