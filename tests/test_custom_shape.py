@@ -83,3 +83,42 @@ def test_custom_shape_surface_on_the_gpu():
     from roborugby_amd.config import custom_preset
     q = custom_preset(1, 1, 2, 1)
     assert (q.nr, q.nb) == (2, 3) and build.shape_lib_path(1, 1, 2, 1).endswith("libroborugby_amd_1x1_2x1.so")
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_on_demand_compile_of_a_four_lane_shape_and_parity_with_the_oracle():
+    """1 + 1 robots, 2 + 1 balls: no library for it ships -- BatchedRoboRugbyEnv compiles one on the spot (hipcc on the GPU box, about
+    half a minute), four lanes per arena: the narrow phases' "fewer than eight lanes" variants with three balls, a combination none
+    of the built shapes has.  Contact-dense states against the oracle (1e-9, equal fault bits), reset draw for draw."""
+    import torch
+    import roborugby_amd as rr
+    import adversarial as adv
+    from roborugby_amd.config import custom_preset
+    from test_differential_adversarial import _compare
+    p = custom_preset(1, 1, 2, 1, name="Y")
+    n = 1500
+    robots, balls, actions = adv.make_states("Y", n, seed=9)
+    env = rr.BatchedRoboRugbyEnv(n, preset=p, time_limit=False, auto_reset=False)
+    assert env.lanes_per_env() == 4
+    env.set_poses(robots, balls)
+    o, r, d, info = env.step_f64(torch.as_tensor(actions))
+    st = {k: v.cpu().numpy() for k, v in env.get_state().items()}
+    o, r, d, status = o.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy(), info.status.cpu().numpy()
+    ok = faults = knife = 0
+    for a in range(0, n, 3):
+        res, ost = adv.oracle_step("Y", robots[a], balls[a], actions[a])
+        g_res = dict(status=int(status[a]) & 0xFFFF, obs=o[a], reward=float(r[a]), done=bool(d[a]))
+        g_st = {k: st[k][a] for k in ("robots", "robots_i", "balls")}
+        v = _compare("Y", res, ost, g_res, g_st, ("Y", a), (robots[a], balls[a], actions[a]))
+        ok += v == "ok"; faults += v == "fault"; knife += v == "knife"
+    assert ok > 0.5 * (n // 3) and knife <= 0.05 * (n // 3), (ok, faults, knife)
+    env2 = rr.BatchedRoboRugbyEnv(65, preset=p, seed=1234, arena_offset=1000)
+    env2.reset()
+    s2 = {k: v.cpu().numpy() for k, v in env2.get_state().items()}
+    for a in (0, 1, 64):
+        orc = ol.OracleEnv("Y")
+        orc.reset(1234, 1000 + a, 0); orc.reset(1234, 1000 + a, 1)
+        os_ = orc.get_state()
+        assert np.array_equal(os_["robots"][:, [0, 1, 6]], s2["robots"][a][:, [0, 1, 6]]) and np.array_equal(os_["balls"], s2["balls"][a]), a
+    print(f"[Y = 1+1 / 2+1, compiled on demand] {ok} adversarial states match the oracle, {faults} faulted identically, {knife} knife-edge")
